@@ -1,0 +1,324 @@
+"""ctypes binding + NumPy mirrors for the CPU ORACLE (test infrastructure, not product).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  The product package (``video-analysis_amd/video``) never does.
+
+Each function names the reference code it restates (paths relative to the reference
+checkout, e.g. ``video/analysis/video.py:33``); details are in ``va_oracle.c``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libva_oracle.so")
+
+
+def build(force=False):
+    """compile va_oracle.c with gcc (seconds)"""
+    src = os.path.join(_HERE, "va_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libva_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.vao_gauss_ksize.argtypes = [C.c_double, C.c_int]
+        _lib.vao_gauss_taps_q8.argtypes = [C.c_double, C.POINTER(C.c_int), C.c_void_p]
+        _lib.vao_gauss_taps_f32.argtypes = [C.c_double, C.POINTER(C.c_int), C.c_void_p]
+        _lib.vao_gaussian_u8.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_double]
+        _lib.vao_gaussian_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_double]
+        _lib.vao_bg_mean_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                        C.c_size_t]
+        _lib.vao_bg_mean_u8.restype = None
+        _lib.vao_welford_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                        C.c_size_t]
+        _lib.vao_welford_u8.restype = None
+        _lib.vao_bg_ema_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                        C.c_int, C.c_size_t]
+        _lib.vao_bg_ema_f32.restype = None
+        _lib.vao_bg_ema_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                       C.c_int, C.c_size_t]
+        _lib.vao_bg_ema_u8.restype = None
+        _lib.vao_bg_static_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
+        _lib.vao_bg_static_u8.restype = None
+        _lib.vao_time_difference_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        _lib.vao_time_difference_u8.restype = None
+        _lib.vao_threshold_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        _lib.vao_threshold_u8.restype = None
+        _lib.vao_mono_mean_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _lib.vao_mono_mean_u8.restype = None
+        _lib.vao_structuring_element.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        _lib.vao_morph_u8.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6
+        _lib.vao_label_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _lib.vao_label_batch_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4
+        _lib.vao_label_batch_i32.restype = None
+        _lib.vao_region_stats.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.vao_region_stats.restype = None
+        _lib.vao_complete_moments.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.vao_complete_moments.restype = None
+        _lib.vao_chain_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _frames4(a):
+    """view any (H,W) / (H,W,C) / (N,H,W) [is_stack] array as (N,H,W,C)"""
+    a = np.ascontiguousarray(a)
+    return a
+
+
+# ---------------------------------------------------------------------------- Gaussian
+def gauss_ksize(sigma, is_u8=True):
+    return lib().vao_gauss_ksize(float(sigma), int(bool(is_u8)))
+
+
+def gauss_taps_q8(sigma):
+    """OpenCV 8-bit fixed-point taps (unsigned 8.8, sum == 256)"""
+    buf = np.zeros(1024, np.uint16)
+    ks = C.c_int()
+    if lib().vao_gauss_taps_q8(float(sigma), C.byref(ks), _p(buf)):
+        raise ValueError("bad sigma %r" % (sigma,))
+    return buf[:ks.value].copy()
+
+
+def gauss_taps_f32(sigma):
+    buf = np.zeros(1024, np.float32)
+    ks = C.c_int()
+    if lib().vao_gauss_taps_f32(float(sigma), C.byref(ks), _p(buf)):
+        raise ValueError("bad sigma %r" % (sigma,))
+    return buf[:ks.value].copy()
+
+
+def _nhwc(a, frame_ndim_hint=None):
+    """returns (array as contiguous, n, h, w, c) for shapes (H,W), (H,W,C), (N,H,W), (N,H,W,C).
+    3-d input is (N,H,W) unless the last dim is 3 and frame_ndim_hint == 'hwc'."""
+    a = np.ascontiguousarray(a)
+    if a.ndim == 2:
+        return a, 1, a.shape[0], a.shape[1], 1
+    if a.ndim == 3:
+        if frame_ndim_hint == "hwc":
+            return a, 1, a.shape[0], a.shape[1], a.shape[2]
+        return a, a.shape[0], a.shape[1], a.shape[2], 1
+    if a.ndim == 4:
+        return a, a.shape[0], a.shape[1], a.shape[2], a.shape[3]
+    raise ValueError("unsupported shape %r" % (a.shape,))
+
+
+def gaussian_u8(frames, sigma, layout=None):
+    """FilterBlur._process_frame (video/filters.py:388-392) on u8 frames"""
+    a, n, h, w, c = _nhwc(np.asarray(frames, np.uint8), layout)
+    out = np.empty_like(a)
+    if lib().vao_gaussian_u8(_p(a), _p(out), n, h, w, c, float(sigma)):
+        raise ValueError("gaussian_u8 failed")
+    return out
+
+
+def gaussian_f32(frames, sigma, layout=None):
+    """cv2.GaussianBlur on float frames (video/analysis/active_contour.py:108)"""
+    a, n, h, w, c = _nhwc(np.asarray(frames, np.float32), layout)
+    out = np.empty_like(a)
+    if lib().vao_gaussian_f32(_p(a), _p(out), n, h, w, c, float(sigma)):
+        raise ValueError("gaussian_f32 failed")
+    return out
+
+
+# -------------------------------------------------------------------------- background
+def measure_mean_numpy(frames):
+    """LITERAL NumPy restatement of measure_mean (video/analysis/video.py:26-35)."""
+    mean = np.zeros(frames.shape[1:])
+    for n, frame in enumerate(frames):
+        mean = mean * n / (n + 1) + frame / (n + 1)
+    return mean
+
+
+def measure_mean_std_numpy(frames):
+    """LITERAL NumPy restatement of measure_mean_std (video/analysis/video.py:39-55)."""
+    mean = np.zeros(frames.shape[1:])
+    M2 = np.zeros(frames.shape[1:])
+    n = -1
+    for n, frame in enumerate(frames):
+        delta = frame - mean
+        mean = mean + delta / (n + 1)
+        M2 = M2 + delta * (frame - mean)
+    if n < 2:
+        return frame, 0
+    return mean, np.sqrt(M2 / n)
+
+
+def bg_mean_u8(frames, mean=None, n_seen=0, want_diff=True):
+    """FilterBackground(mode='mean'): returns (diff u8, mean f64 updated copy)"""
+    a = np.ascontiguousarray(frames, np.uint8)
+    px = int(np.prod(a.shape[1:]))
+    mean = np.zeros(a.shape[1:], np.float64) if mean is None else np.array(mean, np.float64)
+    diff = np.empty_like(a) if want_diff else None
+    lib().vao_bg_mean_u8(_p(a), _p(diff), _p(mean), int(n_seen), a.shape[0], px)
+    return diff, mean
+
+
+def welford_u8(frames, mean=None, m2=None, n_seen=0):
+    a = np.ascontiguousarray(frames, np.uint8)
+    px = int(np.prod(a.shape[1:]))
+    mean = np.zeros(a.shape[1:], np.float64) if mean is None else np.array(mean, np.float64)
+    m2 = np.zeros(a.shape[1:], np.float64) if m2 is None else np.array(m2, np.float64)
+    lib().vao_welford_u8(_p(a), _p(mean), _p(m2), int(n_seen), a.shape[0], px)
+    return mean, m2
+
+
+def bg_ema_f32(frames, bg=None, n_seen=0, rate=0.02):
+    a = np.ascontiguousarray(frames, np.float32)
+    px = int(np.prod(a.shape[1:]))
+    bg = np.zeros(a.shape[1:], np.float32) if bg is None else np.array(bg, np.float32)
+    diff = np.empty_like(a)
+    lib().vao_bg_ema_f32(_p(a), _p(diff), _p(bg), int(n_seen), float(rate), a.shape[0], px)
+    return diff, bg
+
+
+def bg_ema_u8(frames, bg=None, n_seen=0, rate=0.02):
+    a = np.ascontiguousarray(frames, np.uint8)
+    px = int(np.prod(a.shape[1:]))
+    bg = np.zeros(a.shape[1:], np.float32) if bg is None else np.array(bg, np.float32)
+    diff = np.empty_like(a)
+    lib().vao_bg_ema_u8(_p(a), _p(diff), _p(bg), int(n_seen), float(rate), a.shape[0], px)
+    return diff, bg
+
+
+def bg_static_u8(frames, bg):
+    a = np.ascontiguousarray(frames, np.uint8)
+    px = int(np.prod(a.shape[1:]))
+    bg = np.ascontiguousarray(bg, np.float64)
+    diff = np.empty_like(a)
+    lib().vao_bg_static_u8(_p(a), _p(diff), _p(bg), a.shape[0], px)
+    return diff
+
+
+def time_difference_u8(this_frame, prev_frame):
+    """FilterTimeDifference._compare_frames (video/filters.py:564-568)"""
+    a = np.ascontiguousarray(this_frame, np.uint8)
+    b = np.ascontiguousarray(prev_frame, np.uint8)
+    out = np.empty(a.shape, np.int16)
+    lib().vao_time_difference_u8(_p(a), _p(b), _p(out), a.size)
+    return out
+
+
+# ------------------------------------------------------------- threshold / mono / morph
+def threshold_u8(frames, thresh, maxval=255):
+    a = np.ascontiguousarray(frames, np.uint8)
+    out = np.empty_like(a)
+    lib().vao_threshold_u8(_p(a), _p(out), a.size, int(thresh), int(maxval))
+    return out
+
+
+def mono_mean_u8(frames):
+    """FilterMonochrome(mode='mean') (video/filters.py:365-366)"""
+    a = np.ascontiguousarray(frames, np.uint8)
+    assert a.shape[-1] == 3
+    out = np.empty(a.shape[:-1], np.uint8)
+    lib().vao_mono_mean_u8(_p(a), _p(out), out.size)
+    return out
+
+
+ERODE, DILATE = 0, 1
+RECT, CROSS, ELLIPSE = 0, 1, 2
+
+
+def structuring_element(shape, ksize):
+    e = np.zeros((ksize, ksize), np.uint8)
+    if lib().vao_structuring_element(int(shape), int(ksize), _p(e)):
+        raise ValueError("bad ksize")
+    return e
+
+
+def morph_u8(frames, op, shape=RECT, ksize=3):
+    """cv2.erode / cv2.dilate (video/analysis/image.py:248-251)"""
+    a, n, h, w, c = _nhwc(np.asarray(frames, np.uint8))
+    assert c == 1
+    out = np.empty_like(a)
+    if lib().vao_morph_u8(_p(a), _p(out), n, h, w, int(op), int(shape), int(ksize)):
+        raise ValueError("morph failed")
+    return out
+
+
+# ------------------------------------------------------------------- labelling / stats
+def label(mask, connectivity=4):
+    """ndimage.measurements.label(mask) (video/analysis/regions.py:162) -> (labels, count)"""
+    m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+    assert m.ndim == 2
+    lab = np.empty(m.shape, np.int32)
+    cnt = lib().vao_label_i32(_p(m), _p(lab), m.shape[0], m.shape[1], int(connectivity))
+    return lab, cnt
+
+
+def label_batch(masks, connectivity=4):
+    m = np.ascontiguousarray(np.asarray(masks) != 0, np.uint8)
+    assert m.ndim == 3
+    lab = np.empty(m.shape, np.int32)
+    cnt = np.empty(m.shape[0], np.int32)
+    lib().vao_label_batch_i32(_p(m), _p(lab), _p(cnt), m.shape[0], m.shape[1], m.shape[2],
+                              int(connectivity))
+    return lab, cnt
+
+
+STAT_NAMES = ("area", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03",
+              "xmin", "ymin", "xmax", "ymax", "_r0", "_r1")
+
+
+def region_stats(labels, count):
+    lab = np.ascontiguousarray(labels, np.int32)
+    st = np.zeros((max(int(count), 0), 16), np.int64)
+    if count > 0:
+        lib().vao_region_stats(_p(lab), lab.shape[0], lab.shape[1], int(count), _p(st))
+    return st
+
+
+def complete_moments(m10):
+    """spatial -> central + normalised moments (cv2.moments' completeMomentState order)"""
+    m = np.ascontiguousarray(m10, np.float64)
+    assert m.shape == (10,)
+    out = np.zeros(14, np.float64)
+    lib().vao_complete_moments(_p(m), _p(out))
+    return out
+
+
+def get_largest_region(mask, ret_area=False, connectivity=4):
+    """get_largest_region (video/analysis/regions.py:159-174) incl. first-max tie rule"""
+    labels, num = label(mask, connectivity)
+    if num == 0:
+        raise ValueError("attempt to get argmax of an empty sequence")
+    areas = region_stats(labels, num)[:, 0]
+    label_max = int(np.argmax(areas)) + 1
+    if ret_area:
+        return labels == label_max, int(areas[label_max - 1])
+    return labels == label_max
+
+
+def chain_u8(frames, sigma, thresh, morph_ksize=0, connectivity=4, mean=None, n_seen=0,
+             want_mask=True, want_labels=True):
+    """bg(mean) -> blur -> threshold -> [dilate,erode k x k] -> label, one batch"""
+    a = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = a.shape
+    mean = np.zeros((h, w), np.float64) if mean is None else np.array(mean, np.float64)
+    mask = np.empty((n, h, w), np.uint8) if want_mask else None
+    labels = np.empty((n, h, w), np.int32) if (want_labels and connectivity) else None
+    counts = np.zeros(n, np.int32)
+    rc = lib().vao_chain_u8(_p(a), n, h, w, _p(mean), int(n_seen), float(sigma), int(thresh),
+                            int(morph_ksize), int(connectivity), _p(mask), _p(labels),
+                            _p(counts))
+    if rc:
+        raise ValueError("chain failed")
+    return mask, labels, counts, mean

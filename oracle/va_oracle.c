@@ -1,0 +1,634 @@
+/*
+ * va_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE)
+ *
+ * A plain-C restatement of the reference's per-frame hot path
+ * (david-zwicker/video-analysis, `video.filters` chain + `video.analysis` image ops).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product path (video-analysis_amd/) never does.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - labelling (A7)      : PINNED against scipy.ndimage.label, the exact call the
+ *                           reference makes (video/analysis/regions.py:162).
+ *   - running mean (A2)   : PINNED against the literal NumPy formula of
+ *                           video/analysis/video.py:33 and :48-50.
+ *   - morphology (A6)     : PINNED against scipy.ndimage grey_erosion/grey_dilation with
+ *                           constant neutral border (OpenCV's documented default border).
+ *   - raw moments (A9)    : PINNED against a direct NumPy sum of x^p y^q.
+ *   - Gaussian blur (A1)  : PARITY UNPINNED against OpenCV itself (cv2 is not installed,
+ *                           the reference holds no tests/vectors). It follows OpenCV's
+ *                           published 8-bit fixed-point algorithm (see vao_gauss_taps_q8)
+ *                           and is sanity-bounded against scipy.ndimage.gaussian_filter.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define VAO_MAX_TAPS 1024
+
+/* OpenCV cvRound(): round-half-to-even (lrint in the default rounding mode). */
+static int cv_round(double v) { return (int)lrint(v); }
+
+/* BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba), as cv::borderInterpolate does it,
+ * including the repeated reflection needed when the kernel is wider than the image. */
+static int reflect101(int p, int len)
+{
+    if (len == 1)
+        return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0)
+            p = -p;
+        else
+            p = 2 * (len - 1) - p;
+    }
+    return p;
+}
+
+/* ------------------------------------------------------------------------------------
+ * A1  FilterBlur._process_frame  (video/filters.py:388-392):
+ *         cv2.GaussianBlur(frame.astype(np.uint8), (0, 0), sigma)
+ * OpenCV (>=4.5) 8-bit path: ksize = cvRound(6*sigma+1)|1; taps = exp(-x^2/(2 sigma^2))
+ * normalised in double, quantised to unsigned 8.8 fixed point with error diffusion from
+ * the tails inwards, centre tap = 256 - sum(others); row pass u8*q8.8 -> u16; column pass
+ * accumulates u32 and stores (acc + 2^15) >> 16.
+ * ---------------------------------------------------------------------------------- */
+int vao_gauss_ksize(double sigma, int is_u8)
+{
+    int k = cv_round(sigma * (is_u8 ? 3 : 4) * 2 + 1) | 1;
+    return k;
+}
+
+/* normalised double taps: getGaussianKernelBitExact (IEEE double, libm exp) */
+static int gauss_taps_f64(double sigma, int n, double *out)
+{
+    if (n < 1 || n > VAO_MAX_TAPS || !(sigma > 0))
+        return -1;
+    int n2 = (n - 1) / 2;
+    double scale2x = -0.125 / (sigma * sigma);
+    double sum = 0.0;
+    double *values = (double *)malloc(sizeof(double) * (n2 + 1));
+    for (int i = 0, x = 1 - n; i < n2; i++, x += 2) {
+        double t = exp((double)(x * x) * scale2x);
+        values[i] = t;
+        sum += t;
+    }
+    sum *= 2.0;
+    sum += 1.0;
+    double mul1 = 1.0 / sum;
+    for (int i = 0; i < n2; i++) {
+        double t = values[i] * mul1;
+        out[i] = t;
+        out[n - 1 - i] = t;
+    }
+    out[n2] = 1.0 * mul1;
+    free(values);
+    return 0;
+}
+
+int vao_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps)
+{
+    int n = vao_gauss_ksize(sigma, 1);
+    double k[VAO_MAX_TAPS];
+    if (gauss_taps_f64(sigma, n, k))
+        return -1;
+    int n2 = n / 2;
+    double err = 0.0;
+    int64_t sum = 0;
+    for (int i = 0; i < n2; i++) {
+        double adj = k[i] * 256.0 + err;
+        int64_t v0 = cv_round(adj);
+        err = adj - (double)v0;
+        taps[i] = (uint16_t)v0;
+        taps[n - 1 - i] = (uint16_t)v0;
+        sum += v0;
+    }
+    sum *= 2;
+    taps[n2] = (uint16_t)(256 - sum);
+    *ksize_out = n;
+    return 0;
+}
+
+int vao_gauss_taps_f32(double sigma, int *ksize_out, float *taps)
+{
+    int n = vao_gauss_ksize(sigma, 0);
+    double k[VAO_MAX_TAPS];
+    if (gauss_taps_f64(sigma, n, k))
+        return -1;
+    for (int i = 0; i < n; i++)
+        taps[i] = (float)k[i];
+    *ksize_out = n;
+    return 0;
+}
+
+/* frames: (n, h, w, c) u8 contiguous; each channel independently */
+int vao_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
+                    double sigma)
+{
+    uint16_t taps[VAO_MAX_TAPS];
+    int ks;
+    if (vao_gauss_taps_q8(sigma, &ks, taps))
+        return -1;
+    int r = ks / 2;
+    size_t fsz = (size_t)h * w * c;
+    uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * fsz);
+    int *xi = (int *)malloc(sizeof(int) * (size_t)(w + 2 * r));
+    int *yi = (int *)malloc(sizeof(int) * (size_t)(h + 2 * r));
+    for (int x = -r; x < w + r; x++)
+        xi[x + r] = reflect101(x, w);
+    for (int y = -r; y < h + r; y++)
+        yi[y + r] = reflect101(y, h);
+    for (int f = 0; f < n; f++) {
+        const uint8_t *s = src + f * fsz;
+        uint8_t *d = dst + f * fsz;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                for (int ch = 0; ch < c; ch++) {
+                    uint32_t acc = 0;
+                    for (int i = 0; i < ks; i++)
+                        acc += (uint32_t)taps[i] * s[((size_t)y * w + xi[x + i]) * c + ch];
+                    tmp[((size_t)y * w + x) * c + ch] = (uint16_t)acc; /* <= 255*256 */
+                }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                for (int ch = 0; ch < c; ch++) {
+                    uint32_t acc = 0;
+                    for (int j = 0; j < ks; j++)
+                        acc += (uint32_t)taps[j] * tmp[((size_t)yi[y + j] * w + x) * c + ch];
+                    uint32_t v = (acc + 32768u) >> 16;
+                    d[((size_t)y * w + x) * c + ch] = (uint8_t)(v > 255 ? 255 : v);
+                }
+    }
+    free(tmp);
+    free(xi);
+    free(yi);
+    return 0;
+}
+
+/* Float path: cv2.GaussianBlur on a non-8-bit image, as at
+ * video/analysis/active_contour.py:108. ksize = cvRound(8*sigma+1)|1, f32 taps; row pass =
+ * in-order fmaf chain over the taps, column pass = centre tap then symmetric pairs
+ * (S[+k]+S[-k]) folded with fmaf (OpenCV's RowVec_32f / SymmColumnVec_32f order). */
+int vao_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, double sigma)
+{
+    float taps[VAO_MAX_TAPS];
+    int ks;
+    if (vao_gauss_taps_f32(sigma, &ks, taps))
+        return -1;
+    int r = ks / 2;
+    size_t fsz = (size_t)h * w * c;
+    float *tmp = (float *)malloc(sizeof(float) * fsz);
+    int *xi = (int *)malloc(sizeof(int) * (size_t)(w + 2 * r));
+    int *yi = (int *)malloc(sizeof(int) * (size_t)(h + 2 * r));
+    for (int x = -r; x < w + r; x++)
+        xi[x + r] = reflect101(x, w);
+    for (int y = -r; y < h + r; y++)
+        yi[y + r] = reflect101(y, h);
+    for (int f = 0; f < n; f++) {
+        const float *s = src + f * fsz;
+        float *d = dst + f * fsz;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                for (int ch = 0; ch < c; ch++) {
+                    float acc = 0.0f;
+                    for (int i = 0; i < ks; i++)
+                        acc = fmaf(s[((size_t)y * w + xi[x + i]) * c + ch], taps[i], acc);
+                    tmp[((size_t)y * w + x) * c + ch] = acc;
+                }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                for (int ch = 0; ch < c; ch++) {
+                    float acc = fmaf(tmp[((size_t)yi[y + r] * w + x) * c + ch], taps[r], 0.0f);
+                    for (int k = 1; k <= r; k++) {
+                        float a = tmp[((size_t)yi[y + r + k] * w + x) * c + ch];
+                        float b = tmp[((size_t)yi[y + r - k] * w + x) * c + ch];
+                        acc = fmaf(a + b, taps[r + k], acc);
+                    }
+                    d[((size_t)y * w + x) * c + ch] = acc;
+                }
+    }
+    free(tmp);
+    free(xi);
+    free(yi);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * A2  measure_mean (video/analysis/video.py:26-35):
+ *         mean = mean*n/(n + 1) + frame/(n + 1)          (float64, this operation order)
+ *     BUILD-DEFINED FilterBackground(mode='mean'): emit sat_u8(trunc(|frame - bg_prev|)),
+ *     then update bg with the formula above. `n_seen` = frames folded into `mean` so far.
+ * ---------------------------------------------------------------------------------- */
+void vao_bg_mean_u8(const uint8_t *frames, uint8_t *diff_out, double *mean, int64_t n_seen,
+                    int n, size_t px)
+{
+    for (int f = 0; f < n; f++) {
+        double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
+        const uint8_t *s = frames + (size_t)f * px;
+        for (size_t i = 0; i < px; i++) {
+            double fr = (double)s[i];
+            if (diff_out) {
+                double d = fabs(fr - mean[i]);
+                d = trunc(d);
+                diff_out[(size_t)f * px + i] = (uint8_t)(d > 255.0 ? 255.0 : d);
+            }
+            mean[i] = mean[i] * dn / dn1 + fr / dn1;
+        }
+    }
+}
+
+/* measure_mean_std (video/analysis/video.py:39-55), Welford:
+ *   delta = frame - mean; mean = mean + delta/(n+1); M2 = M2 + delta*(frame - mean) */
+void vao_welford_u8(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
+                    size_t px)
+{
+    for (int f = 0; f < n; f++) {
+        double dn1 = (double)(n_seen + f + 1);
+        const uint8_t *s = frames + (size_t)f * px;
+        for (size_t i = 0; i < px; i++) {
+            double fr = (double)s[i];
+            double delta = fr - mean[i];
+            mean[i] = mean[i] + delta / dn1;
+            m2[i] = m2[i] + delta * (fr - mean[i]);
+        }
+    }
+}
+
+/* BUILD-DEFINED FilterBackground(mode='ema') (no reference counterpart):
+ *   out = |frame - bg|;  bg = bg + rate*(frame - bg)      all float32, no contraction.
+ * The first frame ever seen (n_seen == 0) initialises bg = frame and emits 0. */
+void vao_bg_ema_f32(const float *frames, float *diff_out, float *bg, int64_t n_seen, float rate,
+                    int n, size_t px)
+{
+    for (int f = 0; f < n; f++) {
+        const float *s = frames + (size_t)f * px;
+        for (size_t i = 0; i < px; i++) {
+            float fr = s[i];
+            if (n_seen + f == 0)
+                bg[i] = fr;
+            float d = fr - bg[i];
+            if (diff_out)
+                diff_out[(size_t)f * px + i] = fabsf(d);
+            float step = rate * d; /* built with -ffp-contract=off: no fma */
+            bg[i] = bg[i] + step;
+        }
+    }
+}
+
+/* BUILD-DEFINED u8 variant of the EMA background: state float32,
+ *   out = sat_u8(trunc(|frame - bg|)); bg = bg + rate*(frame - bg). */
+void vao_bg_ema_u8(const uint8_t *frames, uint8_t *diff_out, float *bg, int64_t n_seen,
+                   float rate, int n, size_t px)
+{
+    for (int f = 0; f < n; f++) {
+        const uint8_t *s = frames + (size_t)f * px;
+        for (size_t i = 0; i < px; i++) {
+            float fr = (float)s[i];
+            if (n_seen + f == 0)
+                bg[i] = fr;
+            float d = fr - bg[i];
+            if (diff_out) {
+                float a = truncf(fabsf(d));
+                diff_out[(size_t)f * px + i] = (uint8_t)(a > 255.0f ? 255.0f : a);
+            }
+            float step = rate * d;
+            bg[i] = bg[i] + step;
+        }
+    }
+}
+
+/* static background: out = sat_u8(trunc(|frame - bg|)), bg float64 unchanged */
+void vao_bg_static_u8(const uint8_t *frames, uint8_t *diff_out, const double *bg, int n,
+                      size_t px)
+{
+    for (int f = 0; f < n; f++)
+        for (size_t i = 0; i < px; i++) {
+            double d = trunc(fabs((double)frames[(size_t)f * px + i] - bg[i]));
+            diff_out[(size_t)f * px + i] = (uint8_t)(d > 255.0 ? 255.0 : d);
+        }
+}
+
+/* A3  FilterTimeDifference._compare_frames (video/filters.py:564-568):
+ *         this_frame.astype(int16) - prev_frame      -> int16 */
+void vao_time_difference_u8(const uint8_t *this_frame, const uint8_t *prev_frame, int16_t *out,
+                            size_t count)
+{
+    for (size_t i = 0; i < count; i++)
+        out[i] = (int16_t)((int16_t)this_frame[i] - (int16_t)prev_frame[i]);
+}
+
+/* A4  BUILD-DEFINED FilterThreshold: strict `>` like the reference's boolean-mask idiom
+ * (video/analysis/image.py:282,288,304) == cv2.THRESH_BINARY. */
+void vao_threshold_u8(const uint8_t *src, uint8_t *dst, size_t count, int thresh, int maxval)
+{
+    for (size_t i = 0; i < count; i++)
+        dst[i] = (uint8_t)(src[i] > thresh ? maxval : 0);
+}
+
+/* A5  FilterMonochrome(mode='mean') (video/filters.py:365-366):
+ *         np.mean(frame, axis=2).astype(frame.dtype)  -- f64 mean of 3 channels, truncation.
+ * NumPy's mean adds the channels in f64 (pairwise == sequential for 3 items) then divides. */
+void vao_mono_mean_u8(const uint8_t *src, uint8_t *dst, size_t pixels)
+{
+    for (size_t i = 0; i < pixels; i++) {
+        double s = (double)src[3 * i] + (double)src[3 * i + 1] + (double)src[3 * i + 2];
+        dst[i] = (uint8_t)(s / 3.0);
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * A6  cv2.erode / cv2.dilate with cv2.getStructuringElement (video/analysis/image.py:248-251)
+ * op: 0 = erode (min), 1 = dilate (max). shape: 0 = RECT, 1 = CROSS, 2 = ELLIPSE.
+ * anchor = centre (k/2); pixels outside the image never win (OpenCV's default
+ * morphologyDefaultBorderValue()).
+ * ---------------------------------------------------------------------------------- */
+int vao_structuring_element(int shape, int ksize, uint8_t *elem /* ksize*ksize */)
+{
+    if (ksize < 1)
+        return -1;
+    int r = ksize / 2, c = ksize / 2;
+    double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < ksize; i++) {
+        int j1 = 0, j2 = 0;
+        if (shape == 0 || (shape == 1 && i == r))
+            j2 = ksize;
+        else if (shape == 1) {
+            j1 = c;
+            j2 = j1 + 1;
+        } else {
+            int dy = i - r;
+            if (abs(dy) <= r) {
+                int dx = cv_round(c * sqrt((r * r - dy * dy) * inv_r2));
+                j1 = c - dx > 0 ? c - dx : 0;
+                j2 = c + dx + 1 < ksize ? c + dx + 1 : ksize;
+            }
+        }
+        for (int j = 0; j < ksize; j++)
+            elem[i * ksize + j] = (uint8_t)(j >= j1 && j < j2);
+    }
+    return 0;
+}
+
+int vao_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op, int shape,
+                 int ksize)
+{
+    uint8_t *elem = (uint8_t *)malloc((size_t)ksize * ksize);
+    if (vao_structuring_element(shape, ksize, elem)) {
+        free(elem);
+        return -1;
+    }
+    int a = ksize / 2;
+    if (shape == 0) {
+        /* rectangle: separable (1 x k then k x 1), identical result */
+        uint8_t *t = (uint8_t *)malloc((size_t)h * w);
+        for (int f = 0; f < n; f++) {
+            const uint8_t *s = src + (size_t)f * h * w;
+            uint8_t *d = dst + (size_t)f * h * w;
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    int lo = x - a < 0 ? 0 : x - a, hi = x - a + ksize > w ? w : x - a + ksize;
+                    int best = op ? 0 : 255;
+                    for (int xx = lo; xx < hi; xx++) {
+                        int v = s[(size_t)y * w + xx];
+                        if (op ? v > best : v < best)
+                            best = v;
+                    }
+                    t[(size_t)y * w + x] = (uint8_t)best;
+                }
+            for (int y = 0; y < h; y++) {
+                int lo = y - a < 0 ? 0 : y - a, hi = y - a + ksize > h ? h : y - a + ksize;
+                for (int x = 0; x < w; x++) {
+                    int best = op ? 0 : 255;
+                    for (int yy = lo; yy < hi; yy++) {
+                        int v = t[(size_t)yy * w + x];
+                        if (op ? v > best : v < best)
+                            best = v;
+                    }
+                    d[(size_t)y * w + x] = (uint8_t)best;
+                }
+            }
+        }
+        free(t);
+        free(elem);
+        return 0;
+    }
+    for (int f = 0; f < n; f++) {
+        const uint8_t *s = src + (size_t)f * h * w;
+        uint8_t *d = dst + (size_t)f * h * w;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int best = op ? 0 : 255;
+                for (int i = 0; i < ksize; i++) {
+                    int yy = y + i - a;
+                    if (yy < 0 || yy >= h)
+                        continue;
+                    for (int j = 0; j < ksize; j++) {
+                        int xx = x + j - a;
+                        if (xx < 0 || xx >= w || !elem[i * ksize + j])
+                            continue;
+                        int v = s[(size_t)yy * w + xx];
+                        if (op ? v > best : v < best)
+                            best = v;
+                    }
+                }
+                d[(size_t)y * w + x] = (uint8_t)best;
+            }
+    }
+    free(elem);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * A7  get_largest_region (video/analysis/regions.py:159-174):
+ *         labels, num_features = ndimage.measurements.label(mask)
+ * 4-connectivity by default (SciPy's default structure), any non-zero = foreground, int32
+ * labels 1..L numbered in raster order of each component's first pixel.
+ * Two-pass union-find with min-index roots, then raster renumbering.
+ * ---------------------------------------------------------------------------------- */
+static int32_t uf_find(int32_t *p, int32_t a)
+{
+    while (p[a] != a) {
+        p[a] = p[p[a]];
+        a = p[a];
+    }
+    return a;
+}
+static void uf_union(int32_t *p, int32_t a, int32_t b)
+{
+    a = uf_find(p, a);
+    b = uf_find(p, b);
+    if (a < b)
+        p[b] = a;
+    else if (b < a)
+        p[a] = b;
+}
+
+int vao_label_i32(const uint8_t *mask, int32_t *labels, int h, int w, int connectivity)
+{
+    size_t px = (size_t)h * w;
+    int32_t *p = (int32_t *)malloc(sizeof(int32_t) * (px ? px : 1));
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int32_t i = y * w + x;
+            if (!mask[i]) {
+                p[i] = -1;
+                continue;
+            }
+            p[i] = i;
+            if (x > 0 && mask[i - 1])
+                uf_union(p, i, i - 1);
+            if (y > 0) {
+                if (mask[i - w])
+                    uf_union(p, i, i - w);
+                if (connectivity == 8) {
+                    if (x > 0 && mask[i - w - 1])
+                        uf_union(p, i, i - w - 1);
+                    if (x + 1 < w && mask[i - w + 1])
+                        uf_union(p, i, i - w + 1);
+                }
+            }
+        }
+    int32_t next = 0;
+    for (size_t i = 0; i < px; i++) {
+        if (p[i] < 0) {
+            labels[i] = 0;
+            continue;
+        }
+        int32_t r = uf_find(p, (int32_t)i);
+        if (r == (int32_t)i)
+            labels[i] = ++next; /* first pixel of a new component in raster order */
+        else
+            labels[i] = labels[r];
+    }
+    free(p);
+    return next;
+}
+
+/* batch wrapper: counts[f] = number of components of frame f */
+void vao_label_batch_i32(const uint8_t *mask, int32_t *labels, int32_t *counts, int n, int h,
+                         int w, int connectivity)
+{
+    for (int f = 0; f < n; f++)
+        counts[f] = vao_label_i32(mask + (size_t)f * h * w, labels + (size_t)f * h * w, h, w,
+                                  connectivity);
+}
+
+/* ------------------------------------------------------------------------------------
+ * A7/A8/A9 per-label statistics from a label image.
+ * stats[(l-1)*16 + k], k = 0 area(m00) 1 m10 2 m01 3 m20 4 m11 5 m02 6 m30 7 m21 8 m12
+ * 9 m03 10 xmin 11 ymin 12 xmax 13 ymax 14,15 reserved(0).
+ * Follows np.sum(labels == label) (video/analysis/regions.py:165-166), find_bounding_box
+ * (regions.py:113-149) and cv2.moments(mask.astype(np.uint8)) spatial moments
+ * m_pq = sum x^p y^q (video/analysis/image.py:353) with unit intensity.
+ * ---------------------------------------------------------------------------------- */
+void vao_region_stats(const int32_t *labels, int h, int w, int count, int64_t *stats)
+{
+    memset(stats, 0, sizeof(int64_t) * 16 * (size_t)count);
+    for (int l = 0; l < count; l++) {
+        stats[l * 16 + 10] = w;
+        stats[l * 16 + 11] = h;
+        stats[l * 16 + 12] = -1;
+        stats[l * 16 + 13] = -1;
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int32_t l = labels[(size_t)y * w + x];
+            if (l <= 0 || l > count)
+                continue;
+            int64_t *s = stats + (size_t)(l - 1) * 16;
+            int64_t X = x, Y = y;
+            s[0] += 1;
+            s[1] += X;
+            s[2] += Y;
+            s[3] += X * X;
+            s[4] += X * Y;
+            s[5] += Y * Y;
+            s[6] += X * X * X;
+            s[7] += X * X * Y;
+            s[8] += X * Y * Y;
+            s[9] += Y * Y * Y;
+            if (X < s[10]) s[10] = X;
+            if (Y < s[11]) s[11] = Y;
+            if (X > s[12]) s[12] = X;
+            if (Y > s[13]) s[13] = Y;
+        }
+}
+
+/* Central and normalised moments from the 10 spatial moments, in the operation order of
+ * OpenCV's completeMomentState (the arithmetic behind cv2.moments used at
+ * video/analysis/image.py:353 and video/analysis/shapes.py:533).
+ * in : m[10] = m00 m10 m01 m20 m11 m02 m30 m21 m12 m03
+ * out: o[14] = mu20 mu11 mu02 mu30 mu21 mu12 mu03 nu20 nu11 nu02 nu30 nu21 nu12 nu03 */
+void vao_complete_moments(const double *m, double *o)
+{
+    double m00 = m[0], m10 = m[1], m01 = m[2], m20 = m[3], m11 = m[4], m02 = m[5];
+    double m30 = m[6], m21 = m[7], m12 = m[8], m03 = m[9];
+    double cx = 0, cy = 0, inv_m00 = 0.0;
+    if (fabs(m00) > 2.220446049250313e-16) {
+        inv_m00 = 1. / m00;
+        cx = m10 * inv_m00;
+        cy = m01 * inv_m00;
+    }
+    double mu20 = m20 - m10 * cx;
+    double mu11 = m11 - m10 * cy;
+    double mu02 = m02 - m01 * cy;
+    o[0] = mu20;
+    o[1] = mu11;
+    o[2] = mu02;
+    o[3] = m30 - cx * (3 * mu20 + cx * m10);
+    mu11 += mu11;
+    o[4] = m21 - cx * (mu11 + cx * m01) - cy * mu20;
+    o[5] = m12 - cy * (mu11 + cy * m10) - cx * mu02;
+    o[6] = m03 - cy * (3 * mu02 + cy * m01);
+    double inv_sqrt_m00 = sqrt(fabs(inv_m00));
+    double s2 = inv_m00 * inv_m00, s3 = s2 * inv_sqrt_m00;
+    o[7] = o[0] * s2;
+    o[8] = o[1] * s2;
+    o[9] = o[2] * s2;
+    o[10] = o[3] * s3;
+    o[11] = o[4] * s3;
+    o[12] = o[5] * s3;
+    o[13] = o[6] * s3;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Whole chain for one batch (the BASELINE.json cfg#2/#3 workload), single-threaded:
+ * bg(mean) -> gaussian(sigma) -> threshold -> [dilate k, erode k (rect)] -> label.
+ * Used by tests for end-to-end parity and by bench.py's cpu_baseline leg.
+ * Any of mask_out / labels_out may be NULL. `mean` is updated in place.
+ * ---------------------------------------------------------------------------------- */
+int vao_chain_u8(const uint8_t *frames, int n, int h, int w, double *mean, int64_t n_seen,
+                 double sigma, int thresh, int morph_ksize, int connectivity,
+                 uint8_t *mask_out, int32_t *labels_out, int32_t *counts_out)
+{
+    size_t px = (size_t)h * w;
+    uint8_t *a = (uint8_t *)malloc(px), *b = (uint8_t *)malloc(px);
+    int32_t *lab = labels_out ? NULL : (int32_t *)malloc(sizeof(int32_t) * px);
+    for (int f = 0; f < n; f++) {
+        vao_bg_mean_u8(frames + f * px, a, mean, n_seen + f, 1, px);
+        if (sigma > 0) {
+            if (vao_gaussian_u8(a, b, 1, h, w, 1, sigma))
+                return -1;
+        } else
+            memcpy(b, a, px);
+        vao_threshold_u8(b, a, px, thresh, 255);
+        if (morph_ksize > 1) {
+            vao_morph_u8(a, b, 1, h, w, 1, 0, morph_ksize);
+            vao_morph_u8(b, a, 1, h, w, 0, 0, morph_ksize);
+        }
+        if (mask_out)
+            memcpy(mask_out + f * px, a, px);
+        if (connectivity) {
+            int32_t *l = labels_out ? labels_out + f * px : lab;
+            int cnt = vao_label_i32(a, l, h, w, connectivity);
+            if (counts_out)
+                counts_out[f] = cnt;
+        }
+    }
+    free(a);
+    free(b);
+    free(lab);
+    return 0;
+}

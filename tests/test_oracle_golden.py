@@ -1,0 +1,197 @@
+"""CPU: the oracle (oracle/va_oracle.c) against the committed known-answer vectors.
+
+The vectors come from scipy.ndimage / literal NumPy restatements of the reference formulas /
+scikit-image (tests/golden/make_golden.py), i.e. from the third-party code the reference
+itself calls -- the reference has no tests or fixtures of its own.
+"""
+import json
+
+import numpy as np
+import pytest
+
+
+def _names(golden):
+    return [str(n) for n in golden["mask_names"]]
+
+
+def test_label_matches_scipy_vectors(golden, oracle):
+    for name in _names(golden):
+        m = golden["mask_" + name]
+        for conn in (4, 8):
+            lab, cnt = oracle.label(m, conn)
+            assert cnt == int(golden["count%d_%s" % (conn, name)]), (name, conn)
+            assert lab.dtype == np.int32
+            assert np.array_equal(lab, golden["labels%d_%s" % (conn, name)]), (name, conn)
+
+
+def test_label_nonzero_is_foreground(oracle):
+    lab, cnt = oracle.label(np.array([[0, 5, 0, 255]], np.uint8))
+    assert cnt == 2 and lab.tolist() == [[0, 1, 0, 2]]
+
+
+def test_areas_largest_region_and_tie(golden, oracle):
+    for name in _names(golden):
+        m = golden["mask_" + name]
+        lab, cnt = oracle.label(m, 4)
+        st = oracle.region_stats(lab, cnt)
+        assert np.array_equal(st[:, 0], golden["areas4_" + name]), name
+        if cnt:
+            big, area = oracle.get_largest_region(m, ret_area=True)
+            assert np.array_equal(big.astype(np.uint8), golden["largest4_" + name]), name
+            assert area == golden["areas4_" + name].max()
+        else:
+            with pytest.raises(ValueError):
+                oracle.get_largest_region(m)
+    # first maximum wins on ties (np.argmax rule, video/analysis/regions.py:169)
+    big = oracle.get_largest_region(golden["mask_tie"])
+    assert big[2, 2] and not big[10, 20]
+
+
+def test_raw_moments_and_bbox(golden, oracle):
+    for name in _names(golden):
+        m = golden["mask_" + name]
+        lab, cnt = oracle.label(m, 4)
+        st = oracle.region_stats(lab, cnt)
+        assert np.array_equal(st[:, :10], golden["lmoments4_" + name]), name
+        for l in range(1, cnt + 1):
+            ys, xs = np.nonzero(lab == l)
+            assert st[l - 1, 10:14].tolist() == [xs.min(), ys.min(), xs.max(), ys.max()]
+        # whole-mask moments == sum over labels
+        if cnt:
+            assert np.array_equal(st[:, :10].sum(0), golden["moments_" + name])
+
+
+def test_central_moments_match_skimage(golden, oracle):
+    sk = json.loads(str(golden["skimage_json"]))
+    if not sk:
+        pytest.skip("fixture was generated without scikit-image")
+    for name, ref in sk.items():
+        raw = golden["moments_" + name].astype(np.float64)
+        out = oracle.complete_moments(raw)
+        got = dict(zip(["mu20", "mu11", "mu02", "mu30", "mu21", "mu12", "mu03"], out[:7]))
+        assert raw[0] == ref["m00"] and raw[1] == ref["m10"] and raw[2] == ref["m01"]
+        scale = max(1.0, abs(raw[6]), abs(raw[9]))
+        for k, v in got.items():
+            assert abs(v - ref[k]) <= 1e-9 * scale, (name, k, v, ref[k])
+
+
+def test_running_mean_is_bit_exact_numpy(golden, oracle):
+    for n in (1, 2, 8, 64, 256):
+        fr = golden["bgframes_%d" % n]
+        diff, mean = oracle.bg_mean_u8(fr)
+        assert np.array_equal(mean, golden["mean_%d" % n])          # bit-exact f64
+        # split batches + carried state == one batch
+        if n >= 8:
+            d1, m1 = oracle.bg_mean_u8(fr[:3])
+            d2, m2 = oracle.bg_mean_u8(fr[3:], mean=m1, n_seen=3)
+            assert np.array_equal(m2, mean)
+            assert np.array_equal(np.concatenate([d1, d2]), diff)
+        # emitted difference: |frame - bg_prev| truncated, bg_prev = mean of earlier frames
+        prev = np.zeros(fr.shape[1:])
+        for k in range(n):
+            exp = np.trunc(np.abs(fr[k] - prev)).astype(np.uint8)
+            assert np.array_equal(diff[k], exp)
+            prev = prev * k / (k + 1) + fr[k] / (k + 1)
+    frc = golden["bgframes_color"]
+    assert np.array_equal(oracle.bg_mean_u8(frc)[1], golden["mean_color"])
+
+
+def test_welford_matches_numpy(golden, oracle):
+    for n in (8, 64, 256):
+        fr = golden["bgframes_%d" % n]
+        mean, m2 = oracle.welford_u8(fr)
+        assert np.array_equal(mean, golden["wmean_%d" % n])
+        assert np.array_equal(np.sqrt(m2 / (n - 1)), golden["wstd_%d" % n])
+
+
+def test_morphology_matches_scipy_vectors(golden, oracle):
+    for nm in ("img", "bin"):
+        im = golden["morph_" + nm]
+        for k in (3, 5, 7):
+            assert np.array_equal(oracle.morph_u8(im, oracle.ERODE, oracle.RECT, k),
+                                  golden["erode_rect%d_%s" % (k, nm)])
+            assert np.array_equal(oracle.morph_u8(im, oracle.DILATE, oracle.RECT, k),
+                                  golden["dilate_rect%d_%s" % (k, nm)])
+        assert np.array_equal(oracle.morph_u8(im, oracle.ERODE, oracle.CROSS, 3),
+                              golden["erode_cross3_" + nm])
+        assert np.array_equal(oracle.morph_u8(im, oracle.DILATE, oracle.CROSS, 3),
+                              golden["dilate_cross3_" + nm])
+
+
+def test_structuring_elements(oracle):
+    assert oracle.structuring_element(oracle.CROSS, 3).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    assert oracle.structuring_element(oracle.RECT, 5).all()
+    e = oracle.structuring_element(oracle.ELLIPSE, 5)
+    assert e.tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1],
+                          [0, 0, 1, 0, 0]]      # cv2.getStructuringElement(MORPH_ELLIPSE,(5,5))
+
+
+def test_gaussian_taps(golden, oracle):
+    for s, ks in ((0.5, 5), (1.0, 7), (2.0, 13), (3.0, 19), (5.0, 31)):
+        t = oracle.gauss_taps_q8(s)
+        assert len(t) == ks == oracle.gauss_ksize(s)          # cvRound(6 sigma + 1) | 1
+        assert int(t.sum()) == 256                            # unity gain in q8.8
+        assert np.array_equal(t, t[::-1])
+        assert np.array_equal(t, golden["taps_q8_%g" % s])
+    t = oracle.gauss_taps_f32(9.0)
+    assert len(t) == 73 == oracle.gauss_ksize(9.0, False)     # cvRound(8 sigma + 1) | 1
+    assert abs(float(t.sum(dtype=np.float64)) - 1) < 1e-6
+    assert np.array_equal(t, golden["taps_f32_9"])
+
+
+def test_gaussian_vectors_and_properties(golden, oracle):
+    from scipy import ndimage
+    for nm in ("imp", "step", "ramp", "noise", "tiny"):
+        im = golden["gin_" + nm]
+        for s in (2.0, 5.0):
+            out = oracle.gaussian_u8(im, s)
+            assert np.array_equal(out, golden["gout_%s_%g" % (nm, s)])
+            if min(im.shape) > 3 * s:      # loose physical sanity bound only (not parity)
+                ref = ndimage.gaussian_filter(im.astype(float), s, mode="mirror", truncate=3.0)
+                assert np.abs(out - ref).max() <= 2.0
+    # constant image is a fixed point (taps sum to exactly 256, rounding is exact)
+    c = np.full((20, 30), 77, np.uint8)
+    assert np.array_equal(oracle.gaussian_u8(c, 5.0), c)
+    # impulse response = outer product of the taps, rounded
+    t = oracle.gauss_taps_q8(2.0).astype(np.int64)
+    imp = np.zeros((41, 41), np.uint8)
+    imp[20, 20] = 255
+    exp = ((np.outer(t, t) * 255 + 32768) >> 16).astype(np.uint8)
+    assert np.array_equal(oracle.gaussian_u8(imp, 2.0)[14:27, 14:27], exp)
+    col = golden["gin_color"]
+    outc = oracle.gaussian_u8(col, 2.0, layout="hwc")
+    assert np.array_equal(outc, golden["gout_color_2"])
+    for ch in range(3):         # channels are independent
+        assert np.array_equal(outc[..., ch], oracle.gaussian_u8(np.ascontiguousarray(col[..., ch]), 2.0))
+    f = golden["gin_f32"]
+    assert np.array_equal(oracle.gaussian_f32(f, 2.0), golden["gout_f32_2"])
+    assert np.array_equal(oracle.gaussian_f32(f, 9.0), golden["gout_f32_9"])
+    ref = ndimage.gaussian_filter(f.astype(np.float64), 2.0, mode="mirror", truncate=4.0)
+    assert np.abs(oracle.gaussian_f32(f, 2.0) - ref).max() < 2e-3
+
+
+def test_threshold_mono_diff(oracle):
+    a = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(oracle.threshold_u8(a, 20), np.where(a > 20, 255, 0))
+    rng = np.random.default_rng(3)
+    c = rng.integers(0, 256, (7, 9, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.mono_mean_u8(c), np.mean(c, axis=2).astype(np.uint8))
+    p = rng.integers(0, 256, (7, 9), dtype=np.uint8)
+    q = rng.integers(0, 256, (7, 9), dtype=np.uint8)
+    assert np.array_equal(oracle.time_difference_u8(p, q), p.astype(np.int16) - q)
+
+
+def test_chain_vectors(golden, oracle):
+    clip = golden["chain_clip"]
+    mask, labels, counts, mean = oracle.chain_u8(clip, 2.0, 20, morph_ksize=5, connectivity=4)
+    assert np.array_equal(mask, golden["chain_mask"])
+    assert np.array_equal(labels, golden["chain_labels"])
+    assert np.array_equal(counts, golden["chain_counts"])
+    assert np.array_equal(mean, golden["chain_mean"])
+    assert counts.max() >= 1
+    # the chain equals its stages
+    diff, mean2 = oracle.bg_mean_u8(clip)
+    m = oracle.threshold_u8(oracle.gaussian_u8(diff, 2.0), 20)
+    m = oracle.morph_u8(oracle.morph_u8(m, oracle.DILATE, oracle.RECT, 5), oracle.ERODE,
+                        oracle.RECT, 5)
+    assert np.array_equal(m, mask) and np.array_equal(mean, mean2)
