@@ -1,0 +1,224 @@
+/*
+ * videoanalysis_hip.h -- C ABI of libvideoanalysis_hip.so (MI355X / gfx950)
+ *
+ * The drop-in boundary for the data-parallel hot path of david-zwicker/video-analysis:
+ * the `video.filters` chain (background subtraction, Gaussian blur, threshold, morphology)
+ * and the per-frame `video.analysis` image ops (labelling, areas, bounding boxes, moments).
+ *
+ * The reference is pure Python and has no FFI of its own; its boundary for this path is the
+ * `VideoFilterBase._process_frame(frame) -> frame` protocol (video/io/base.py:182-189,
+ * 369-380) plus the free functions of the video/analysis modules.  Each entry point below names the
+ * reference call it replaces (paths relative to the reference checkout).  The ctypes stubs a
+ * maintainer would add to the reference are shown in INTEGRATION.md; the build's own Python
+ * host (video-analysis_amd/video/_hip.py) binds exactly these symbols.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 (VA_OK) or a negative errno-style code and
+ *     never throws; va_last_error() gives the message of the calling thread's last failure.
+ *   - "dev" pointers are HIP device pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     kernels are enqueued asynchronously on `stream`; nothing synchronises unless stated.
+ *   - frames are row-major contiguous (N, H, W[, C]); size=(W,H) as in video/io/base.py:119-125.
+ *   - bit masks ("bits") are (N, H, ceil(W/32)) uint32, pixel x <-> bit (x & 31) of word x>>5,
+ *     padding bits are 0.
+ */
+#ifndef VIDEOANALYSIS_HIP_H
+#define VIDEOANALYSIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VA_OK 0
+#define VA_ERR_INVALID (-22) /* EINVAL  bad argument                     */
+#define VA_ERR_NOMEM (-12)   /* ENOMEM  device/host allocation failed   */
+#define VA_ERR_HIP (-5)      /* EIO     a HIP runtime call failed       */
+#define VA_ERR_NODEV (-19)   /* ENODEV  no usable GPU                   */
+#define VA_ERR_RANGE (-34)   /* ERANGE  capacity (max_labels, ...) exceeded */
+
+/* dtypes */
+#define VA_U8 0
+#define VA_F32 1
+/* background modes (BUILD-DEFINED FilterBackground; arithmetic of video/analysis/video.py) */
+#define VA_BG_NONE 0
+#define VA_BG_MEAN 1   /* cumulative mean, float64 state: measure_mean, video/analysis/video.py:33 */
+#define VA_BG_EMA 2    /* bg += rate*(frame-bg), float32 state (no reference counterpart)        */
+#define VA_BG_STATIC 3 /* fixed float64 background image (e.g. a measure_mean() result)          */
+/* morphology */
+#define VA_MORPH_ERODE 0
+#define VA_MORPH_DILATE 1
+#define VA_SHAPE_RECT 0    /* cv2.MORPH_RECT    */
+#define VA_SHAPE_CROSS 1   /* cv2.MORPH_CROSS   (video/analysis/image.py:248) */
+#define VA_SHAPE_ELLIPSE 2 /* cv2.MORPH_ELLIPSE */
+#define VA_MAX_MORPH_OPS 4
+#define VA_STATS_STRIDE 16 /* int64 per label, see va_moments_i64 */
+
+/* ------------------------------------------------------------------ runtime / errors */
+int va_init(int device);               /* select + warm up the GPU; VA_ERR_NODEV if none     */
+int va_device_count(void);             /* number of visible GPUs (0 if none / no driver)     */
+const char *va_version(void);
+const char *va_last_error(void);       /* message for the calling thread's last failure      */
+
+/* device memory helpers, so that a host without torch can drive the library */
+int va_malloc(void **dev_ptr, size_t bytes);
+int va_free(void *dev_ptr);
+int va_host_alloc(void **host_ptr, size_t bytes); /* pinned host memory */
+int va_host_free(void *host_ptr);
+int va_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int va_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int va_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+int va_memset(void *dst_dev, int value, size_t bytes, void *stream);
+int va_stream_sync(void *stream);
+
+/* ------------------------------------------------------------------ A1 Gaussian blur
+ * replaces  cv2.GaussianBlur(frame.astype(np.uint8), (0, 0), sigma)
+ *           FilterBlur._process_frame, video/filters.py:388-392
+ * 8-bit: ksize = cvRound(6 sigma + 1)|1, unsigned 8.8 fixed-point taps, BORDER_REFLECT_101,
+ * each of the `c` interleaved channels independently.  src != dst. */
+int va_gaussian_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int c,
+                   double sigma, void *stream);
+/* replaces  cv2.GaussianBlur(float_image, (0, 0), sigma), video/analysis/active_contour.py:108
+ * ksize = cvRound(8 sigma + 1)|1, float32 taps and fmaf accumulation. */
+int va_gaussian_f32(const float *src_dev, float *dst_dev, int n, int h, int w, int c,
+                    double sigma, void *stream);
+/* analytic taps (host side, no GPU needed): q8.8 taps sum to 256 */
+int va_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps_out, int capacity);
+int va_gauss_taps_f32(double sigma, int *ksize_out, float *taps_out, int capacity);
+
+/* ------------------------------------------------------------------ A2 background model
+ * replaces  mean = mean*n/(n + 1) + frame/(n + 1)       measure_mean, video/analysis/video.py:33
+ * and implements the BUILD-DEFINED FilterBackground: for each of the n frames IN ORDER
+ *     diff = sat_u8(trunc(|frame - bg|))   (f32 frames: |frame - bg|)     then update bg.
+ * mode VA_BG_MEAN  : state = float64[px], n_seen = frames already folded into it
+ * mode VA_BG_EMA   : state = float32[px], rate; the very first frame initialises bg = frame
+ * mode VA_BG_STATIC: state = float64[px], read only
+ * dtype VA_U8 (all modes) or VA_F32 (EMA only).  diff_out may be NULL (state update only). */
+int va_bg_update(int mode, int dtype, const void *frames_dev, void *diff_out_dev,
+                 void *state_dev, int64_t n_seen, double rate, int n, size_t px, void *stream);
+/* replaces  measure_mean_std's Welford update, video/analysis/video.py:48-50 (float64 state) */
+int va_welford_u8(const uint8_t *frames_dev, double *mean_dev, double *m2_dev, int64_t n_seen,
+                  int n, size_t px, void *stream);
+
+/* ------------------------------------------------------------------ A3 / A4 / A5 pointwise
+ * replaces  this_frame.astype(np.int16) - prev_frame, FilterTimeDifference._compare_frames,
+ *           video/filters.py:564-568 */
+int va_time_difference_u8(const uint8_t *this_dev, const uint8_t *prev_dev, int16_t *out_dev,
+                          size_t count, void *stream);
+/* BUILD-DEFINED FilterThreshold; the reference idiom is `frame > t` boolean masks
+ * (video/analysis/image.py:282,288,304):  out = src > thresh ? maxval : 0 */
+int va_threshold_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t count, int thresh,
+                    int maxval, void *stream);
+/* replaces  np.mean(frame, axis=2).astype(frame.dtype), FilterMonochrome._process_frame,
+ *           video/filters.py:365-366 (float64 mean of 3 channels, truncated) */
+int va_mono_mean_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t pixels, void *stream);
+/* replaces  FilterNormalize._process_frame, video/filters.py:126-132, for u8 -> u8:
+ *           clip to [fmin,fmax]; (f - fmin)*alpha + tmin in float64; astype(uint8) */
+int va_normalize_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t count, double fmin,
+                    double fmax, double alpha, double tmin, void *stream);
+
+/* ------------------------------------------------------------------ A6 morphology
+ * replaces  cv2.erode / cv2.dilate(img, cv2.getStructuringElement(shape, (k, k))),
+ *           video/analysis/image.py:248-251; anchor = centre, pixels outside the image never
+ *           win (OpenCV's default border).  src != dst.  (n, h, w) u8. */
+int va_morph_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int op,
+                int shape, int ksize, void *stream);
+
+/* ------------------------------------------------------------------ A7 labelling
+ * replaces  labels, num = ndimage.measurements.label(mask), video/analysis/regions.py:162
+ * any non-zero mask byte is foreground; connectivity 4 (SciPy default) or 8; int32 labels
+ * 1..L numbered in raster order of each component's first pixel; counts[f] = L of frame f.
+ * labels_dev: (n,h,w) int32 (also used as the union-find forest while running).
+ * workspace: va_label_workspace_bytes(n,h,w) bytes of device scratch. */
+size_t va_label_workspace_bytes(int n, int h, int w);
+int va_label_i32(const uint8_t *mask_dev, int32_t *labels_dev, int32_t *counts_dev, int n,
+                 int h, int w, int connectivity, void *workspace_dev, size_t workspace_bytes,
+                 void *stream);
+
+/* ------------------------------------------------------------------ A7/A8/A9 per-label stats
+ * replaces  [np.sum(labels == l) ...], video/analysis/regions.py:165-166;
+ *           find_bounding_box, video/analysis/regions.py:113-149;
+ *           cv2.moments(mask.astype(np.uint8)) spatial moments, video/analysis/image.py:353
+ * stats_dev: (n, max_labels, 16) int64, for label l at [l-1]:
+ *   0 area(m00) 1 m10 2 m01 3 m20 4 m11 5 m02 6 m30 7 m21 8 m12 9 m03
+ *   10 xmin 11 ymin 12 xmax 13 ymax 14,15 reserved
+ * labels above max_labels are ignored (check counts against max_labels on the host). */
+int va_moments_i64(const int32_t *labels_dev, int n, int h, int w, int max_labels,
+                   int64_t *stats_dev, void *stream);
+/* replaces  label_max = np.argmax(areas) + 1; labels == label_max,
+ *           get_largest_region, video/analysis/regions.py:169-174 (first maximum wins).
+ * largest_dev[f] = label_max (0 when the frame is empty); mask_out_dev (nullable) = 0/1 u8. */
+int va_largest_region(const int32_t *labels_dev, const int32_t *counts_dev,
+                      const int64_t *stats_dev, int n, int h, int w, int max_labels,
+                      int32_t *largest_dev, int64_t *largest_area_dev, uint8_t *mask_out_dev,
+                      void *stream);
+
+/* ------------------------------------------------------------------ fused pipeline
+ * One handle per filter chain (not thread-safe; the reference's pull model is single-threaded,
+ * video/io/base.py:207-223).  Runs, for a batch of n <= max_batch frames resident in HBM:
+ *   bg-sub -> Gaussian -> threshold -> morphology ops -> labelling (+ stats)
+ * i.e. FilterBackground -> FilterBlur -> FilterThreshold -> FilterMorphology ->
+ * get_largest_region's label/areas, with bit-packed masks between the stages. */
+typedef struct va_config {
+    int32_t struct_size; /* = sizeof(va_config) */
+    int32_t width, height, channels;
+    int32_t dtype;     /* VA_U8 | VA_F32 */
+    int32_t max_batch; /* frames per va_pipeline_run call, upper bound */
+    int32_t bg_mode;   /* VA_BG_* */
+    float bg_rate;     /* EMA rate */
+    double sigma;      /* <= 0: no blur */
+    int32_t thresh;    /* < 0: stop after the blur (no mask / labels) */
+    int32_t maxval;    /* mask value written to mask_out (default 255) */
+    int32_t morph_count;
+    int32_t morph_op[VA_MAX_MORPH_OPS];
+    int32_t morph_shape[VA_MAX_MORPH_OPS];
+    int32_t morph_ksize[VA_MAX_MORPH_OPS];
+    int32_t connectivity; /* 0: no labelling, 4, 8 */
+    int32_t max_labels;   /* > 0: per-label stats capacity per frame */
+} va_config;
+
+typedef struct va_pipeline va_pipeline_t;
+
+int va_pipeline_create(const va_config *cfg, va_pipeline_t **out);
+int va_pipeline_destroy(va_pipeline_t *p);
+/* frames_dev: (n,H,W[,C]) of cfg.dtype.  Any output may be NULL:
+ *   filtered_out_dev : (n,H,W[,C]) cfg.dtype, the blurred background-subtracted frames
+ *   mask_out_dev     : (n,H,W) u8 0/maxval after threshold + morphology
+ *   labels_out_dev   : (n,H,W) int32
+ *   counts_out_dev   : (n) int32 components per frame
+ *   stats_out_dev    : (n,max_labels,16) int64 */
+int va_pipeline_run(va_pipeline_t *p, const void *frames_dev, int n, void *filtered_out_dev,
+                    uint8_t *mask_out_dev, int32_t *labels_out_dev, int32_t *counts_out_dev,
+                    int64_t *stats_out_dev, void *stream);
+/* background-model state, so that a shard can start mid-video (SURVEY.md 5 "checkpoint") */
+int va_bg_get_state(va_pipeline_t *p, void *state_host, size_t bytes, int64_t *n_seen);
+int va_bg_set_state(va_pipeline_t *p, const void *state_host, size_t bytes, int64_t n_seen);
+size_t va_bg_state_bytes(const va_pipeline_t *p);
+/* name of the implementation used for the Gaussian stage ("fused-lds" / "generic") */
+const char *va_pipeline_describe(const va_pipeline_t *p);
+
+/* ------------------------------------------------------------------ test hooks
+ * Same contracts as va_gaussian_u8 / va_morph_u8, but forcing one implementation so that the
+ * parity tests can compare the generic two-pass Gaussian with the fused LDS kernel, and the
+ * bit-packed morphology used inside the pipeline with the u8 one (binary masks: != 0 -> 255). */
+int va_gaussian_u8_generic(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int c,
+                           double sigma, void *stream);
+int va_morph_bits_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int op,
+                     int shape, int ksize, void *stream);
+
+/* ------------------------------------------------------------------ multi-GPU (RCCL)
+ * Frames shard across ranks with no data-path collective; the only exchange is the final
+ * gather of per-frame object counts.  librccl is resolved lazily (dlopen) on first use.
+ * id_out/id: 128-byte ncclUniqueId produced on rank 0 and distributed by the host. */
+int va_comm_unique_id(uint8_t id_out[128]);
+int va_comm_init(void **comm_out, int world_size, int rank, const uint8_t id[128]);
+int va_gather_counts(void *comm, const int32_t *send_dev, int32_t *recv_dev,
+                     int count_per_rank, void *stream);
+int va_comm_destroy(void *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDEOANALYSIS_HIP_H */

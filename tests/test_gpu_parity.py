@@ -1,0 +1,452 @@
+"""GPU: the HIP path (through the C ABI, via video.ops / video.engine) against the CPU oracle
+and the committed golden vectors.  Bit-exact for every integer/byte/index result and for the
+float64 running mean; the float32 Gaussian is bit-exact against the oracle's fmaf definition
+(tolerance vs real OpenCV per the north star: 1 ULP float32, unverifiable offline).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from video import _hip, ops as _ops
+    _hip.lib()          # raises HipUnavailableError (loudly) if the extension/GPU is missing
+    return _ops
+
+
+def _blob_clip(n, h, w, seed, nblobs=6, salt=0.0):
+    rng = np.random.default_rng(seed)
+    bg = np.clip(rng.normal(100, 10, (h, w)), 0, 255)
+    yy, xx = np.mgrid[:h, :w]
+    pos = rng.uniform(0, 1, (nblobs, 2)) * (w, h)
+    vel = rng.uniform(-3, 3, (nblobs, 2))
+    rad = rng.uniform(min(h, w) / 30 + 2, min(h, w) / 8 + 3, nblobs)
+    out = np.empty((n, h, w), np.uint8)
+    for t in range(n):
+        f = bg + rng.normal(0, 4, (h, w))
+        for (cx, cy), r in zip(pos + vel * t, rad):
+            f[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] += 60
+        if salt:
+            f[rng.random((h, w)) < salt] = 255
+        out[t] = np.clip(f, 0, 255).astype(np.uint8)
+    return out
+
+
+# ---------------------------------------------------------------------------- Gaussian
+@pytest.mark.parametrize("impl", [None, "generic"])
+def test_gaussian_u8_golden(ops, golden, impl):
+    for nm in ("imp", "step", "ramp", "noise", "tiny"):
+        im = golden["gin_" + nm]
+        for s in (2.0, 5.0):
+            out = ops.gaussian_blur(im, s, implementation=impl)
+            assert np.array_equal(out, golden["gout_%s_%g" % (nm, s)]), (nm, s, impl)
+    col = golden["gin_color"]
+    assert np.array_equal(ops.gaussian_blur(col, 2.0, color=True, implementation=impl),
+                          golden["gout_color_2"])
+
+
+@pytest.mark.parametrize("shape,sigma", [((3, 97, 133), 5.0), ((2, 64, 256), 2.0),
+                                         ((1, 200, 517), 3.0), ((2, 31, 40), 1.0),
+                                         ((1, 17, 300), 0.5), ((1, 480, 640), 2.0),
+                                         ((2, 130, 70), 10.0), ((1, 9, 11), 5.0)])
+def test_gaussian_u8_vs_oracle(ops, oracle, shape, sigma):
+    rng = np.random.default_rng(hash(shape) % 1000)
+    im = rng.integers(0, 256, shape, dtype=np.uint8)
+    ref = oracle.gaussian_u8(im, sigma)
+    assert np.array_equal(ops.gaussian_blur(im, sigma), ref)
+    assert np.array_equal(ops.gaussian_blur(im, sigma, implementation="generic"), ref)
+
+
+def test_gaussian_u8_extremes_and_color(ops, oracle):
+    for v in (0, 255, 77):
+        c = np.full((2, 50, 70), v, np.uint8)
+        assert np.array_equal(ops.gaussian_blur(c, 5.0), c)          # unity gain, exact
+    yy, xx = np.mgrid[:64, :96]
+    checker = (((yy + xx) % 2) * 255).astype(np.uint8)
+    assert np.array_equal(ops.gaussian_blur(checker, 2.0), oracle.gaussian_u8(checker, 2.0))
+    rng = np.random.default_rng(5)
+    col = rng.integers(0, 256, (2, 40, 50, 3), dtype=np.uint8)
+    assert np.array_equal(ops.gaussian_blur(col, 3.0, color=True), oracle.gaussian_u8(col, 3.0))
+
+
+def test_gaussian_f32(ops, oracle, golden):
+    f = golden["gin_f32"]
+    assert np.array_equal(ops.gaussian_blur(f, 2.0), golden["gout_f32_2"])
+    assert np.array_equal(ops.gaussian_blur(f, 9.0), golden["gout_f32_9"])
+    rng = np.random.default_rng(8)
+    c = rng.random((2, 33, 47, 3), dtype=np.float32)
+    assert np.array_equal(ops.gaussian_blur(c, 4.0, color=True), oracle.gaussian_f32(c, 4.0))
+
+
+def test_gaussian_1080p_properties(ops, oracle):
+    """full BASELINE size: parity on a crop-sized oracle sample + size-independent properties"""
+    rng = np.random.default_rng(11)
+    im = rng.integers(0, 256, (2, 1080, 1920), dtype=np.uint8)
+    out = ops.gaussian_blur(im, 5.0)
+    assert np.array_equal(out[:1], oracle.gaussian_u8(im[:1], 5.0))
+    assert np.array_equal(out, ops.gaussian_blur(im, 5.0, implementation="generic"))
+    # mean preservation (taps sum to 256; REFLECT_101 keeps mass up to border effects)
+    assert abs(out.mean() - im.mean()) < 0.5
+    # flipping commutes with the (symmetric) filter
+    assert np.array_equal(ops.gaussian_blur(im[:, ::-1, ::-1].copy(), 5.0), out[:, ::-1, ::-1])
+
+
+# -------------------------------------------------------------------------- background
+def test_running_mean_bit_exact(ops, golden, oracle):
+    for n in (1, 2, 8, 64, 256):
+        fr = golden["bgframes_%d" % n]
+        model = ops.BackgroundModel(fr.shape[1:], "mean")
+        diff = model.process(fr)
+        assert np.array_equal(model.state, golden["mean_%d" % n])       # float64, bit-exact
+        assert np.array_equal(diff, oracle.bg_mean_u8(fr)[0])
+        assert model.n_seen == n
+    frc = golden["bgframes_color"]
+    model = ops.BackgroundModel(frc.shape[1:], "mean")
+    model.process(frc, want_diff=False)
+    assert np.array_equal(model.state, golden["mean_color"])
+
+
+def test_running_mean_split_batches_and_odd_sizes(ops, oracle):
+    rng = np.random.default_rng(21)
+    for shape in ((37, 5, 7), (20, 33, 41), (9, 16, 24)):       # px % 8 != 0 and == 0
+        fr = rng.integers(0, 256, shape, dtype=np.uint8)
+        rd, rm = oracle.bg_mean_u8(fr)
+        model = ops.BackgroundModel(shape[1:], "mean")
+        d = np.concatenate([model.process(fr[:4]), model.process(fr[4:5]), model.process(fr[5:])])
+        assert np.array_equal(d, rd) and np.array_equal(model.state, rm)
+        # state export / import (checkpoint-resume of a shard)
+        m2 = ops.BackgroundModel(shape[1:], "mean")
+        m2.process(fr[:6], want_diff=False)
+        m3 = ops.BackgroundModel(shape[1:], "mean")
+        m3.set_state(m2.state, 6)
+        assert np.array_equal(m3.process(fr[6:]), rd[6:])
+
+
+def test_ema_static_welford(ops, oracle, golden):
+    rng = np.random.default_rng(22)
+    fr = rng.integers(0, 256, (30, 12, 20), dtype=np.uint8)
+    rd, rb = oracle.bg_ema_u8(fr, rate=0.05)
+    m = ops.BackgroundModel(fr.shape[1:], "ema", rate=0.05)
+    d = np.concatenate([m.process(fr[:7]), m.process(fr[7:])])
+    assert np.array_equal(d, rd) and np.array_equal(m.state, rb)
+    ff = rng.random((12, 9, 11, 3), dtype=np.float32)
+    rd, rb = oracle.bg_ema_f32(ff, rate=0.02)
+    m = ops.BackgroundModel(ff.shape[1:], "ema", rate=0.02, dtype=np.float32)
+    d = m.process(ff)
+    assert np.array_equal(d, rd) and np.array_equal(m.state, rb)
+    bg = rng.random((12, 20)) * 255
+    m = ops.BackgroundModel((12, 20), "static", background=bg)
+    assert np.array_equal(m.process(fr), oracle.bg_static_u8(fr, bg))
+    for n in (8, 64, 256):
+        fr = golden["bgframes_%d" % n]
+        mean, m2 = ops.welford(fr)
+        assert np.array_equal(mean, golden["wmean_%d" % n])
+        assert np.array_equal(np.sqrt(m2 / (n - 1)), golden["wstd_%d" % n])
+
+
+# --------------------------------------------------------------------------- pointwise
+def test_pointwise_ops(ops, oracle):
+    rng = np.random.default_rng(31)
+    for shape in ((1,), (255,), (7, 9), (3, 64, 100)):
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = rng.integers(0, 256, shape, dtype=np.uint8)
+        for t in (0, 20, 254, 255):
+            assert np.array_equal(ops.threshold(a, t), oracle.threshold_u8(a, t))
+        assert np.array_equal(ops.threshold(a, 100, 1), oracle.threshold_u8(a, 100, 1))
+        assert np.array_equal(ops.time_difference(a, b), a.astype(np.int16) - b)
+    c = rng.integers(0, 256, (5, 17, 23, 3), dtype=np.uint8)
+    assert np.array_equal(ops.mono_mean(c), np.mean(c, axis=3).astype(np.uint8))
+    a = rng.integers(0, 256, (40, 50), dtype=np.uint8)
+    fmin, fmax = 30, 200
+    alpha = 255 / (fmax - fmin)
+    exp = ((np.clip(a, fmin, fmax) - fmin) * alpha + 0).astype(np.uint8)
+    assert np.array_equal(ops.normalize(a, fmin, fmax, alpha, 0), exp)
+
+
+# -------------------------------------------------------------------------- morphology
+def test_morphology_golden_and_oracle(ops, golden, oracle):
+    for nm in ("img", "bin"):
+        im = golden["morph_" + nm]
+        for k in (3, 5, 7):
+            assert np.array_equal(ops.morph(im, "erode", "rect", k), golden["erode_rect%d_%s" % (k, nm)])
+            assert np.array_equal(ops.morph(im, "dilate", "rect", k), golden["dilate_rect%d_%s" % (k, nm)])
+        assert np.array_equal(ops.morph(im, "erode", "cross", 3), golden["erode_cross3_" + nm])
+        assert np.array_equal(ops.morph(im, "dilate", "cross", 3), golden["dilate_cross3_" + nm])
+    rng = np.random.default_rng(41)
+    for shape in ((2, 30, 45), (1, 64, 64), (3, 17, 100), (1, 5, 3), (2, 40, 97)):
+        g = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = ((rng.random(shape) < 0.45) * 255).astype(np.uint8)
+        for op in ("erode", "dilate"):
+            o = oracle.ERODE if op == "erode" else oracle.DILATE
+            for sh, so in (("rect", oracle.RECT), ("cross", oracle.CROSS), ("ellipse", oracle.ELLIPSE)):
+                for k in (1, 2, 3, 4, 5, 9):
+                    assert np.array_equal(ops.morph(g, op, sh, k), oracle.morph_u8(g, o, so, k)), (shape, op, sh, k)
+                    # bit-packed kernel used inside the pipeline == u8 kernel on binary masks
+                    assert np.array_equal(ops.morph(b, op, sh, k, implementation="bits"),
+                                          oracle.morph_u8(b, o, so, k)), (shape, op, sh, k, "bits")
+
+
+# --------------------------------------------------------------------------- labelling
+def test_label_golden_scipy_vectors(ops, golden):
+    for name in [str(n) for n in golden["mask_names"]]:
+        m = golden["mask_" + name]
+        for conn in (4, 8):
+            lab, cnt = ops.label(m, conn)
+            assert cnt == int(golden["count%d_%s" % (conn, name)]), (name, conn)
+            assert lab.dtype == np.int32
+            assert np.array_equal(lab, golden["labels%d_%s" % (conn, name)]), (name, conn)
+    lab, cnt = ops.label(np.array([[0, 5, 0, 255]], np.uint8))
+    assert cnt == 2 and lab.tolist() == [[0, 1, 0, 2]]
+
+
+@pytest.mark.parametrize("h,w,density,seed", [(64, 64, 0.5, 1), (100, 333, 0.6, 2),
+                                               (257, 129, 0.55, 3), (480, 640, 0.45, 4),
+                                               (31, 2100, 0.5, 5), (300, 65, 0.7, 6),
+                                               (128, 4160, 0.59, 7), (1, 500, 0.5, 8),
+                                               (500, 1, 0.5, 9)])
+def test_label_random_vs_oracle(ops, oracle, h, w, density, seed):
+    rng = np.random.default_rng(seed)
+    m = (rng.random((3, h, w)) < density).astype(np.uint8)
+    for conn in (4, 8):
+        lab, cnt = ops.label(m, conn)
+        rl, rc = oracle.label_batch(m, conn)
+        assert np.array_equal(cnt, rc), conn
+        assert np.array_equal(lab, rl), conn
+
+
+def test_label_adversarial(ops, oracle):
+    cases = {}
+    cases["empty"] = np.zeros((40, 70), np.uint8)
+    cases["full"] = np.ones((40, 70), np.uint8)
+    cases["full_wide"] = np.ones((5, 4200), np.uint8)        # runs spanning > 64 words
+    yy, xx = np.mgrid[:200, :300]
+    cases["checker"] = ((yy + xx) % 2).astype(np.uint8)      # 30000 singletons (> 65535/2 ...)
+    big = ((np.mgrid[:600, :512][0] + np.mgrid[:600, :512][1]) % 2).astype(np.uint8)
+    cases["checker_big"] = big                               # 153600 components > 65535
+    serp = np.zeros((201, 333), np.uint8)
+    for y in range(0, 201, 2):
+        serp[y, :] = 1
+        if y + 1 < 201:
+            serp[y + 1, 332 if (y // 2) % 2 == 0 else 0] = 1
+    cases["serpentine"] = serp                               # one component, long dependency chain
+    comb = np.zeros((300, 257), np.uint8)
+    comb[:, ::2] = 1
+    comb[299, :] = 1                                          # vertical teeth joined at the bottom
+    cases["comb"] = comb
+    ucomb = comb[::-1].copy()                                 # joined at the top
+    cases["comb_top"] = ucomb
+    frame = np.zeros((120, 200), np.uint8)
+    frame[0, :] = frame[-1, :] = 1
+    frame[:, 0] = frame[:, -1] = 1
+    frame[40:80, 60:140] = 1
+    cases["border_ring"] = frame
+    tall = np.ones((3000, 33), np.uint8)                      # tall blob: deep union chains
+    cases["tall"] = tall
+    for name, m in cases.items():
+        for conn in (4, 8):
+            lab, cnt = ops.label(m, conn)
+            rl, rc = oracle.label(m, conn)
+            assert cnt == rc, (name, conn, cnt, rc)
+            assert np.array_equal(lab, rl), (name, conn)
+
+
+def test_label_1080p_vs_oracle_and_properties(ops, oracle):
+    clip = _blob_clip(2, 1080, 1920, seed=3, nblobs=40, salt=0.002)
+    m = (clip > 128).astype(np.uint8)
+    lab, cnt = ops.label(m, 4)
+    rl, rc = oracle.label_batch(m, 4)
+    assert np.array_equal(cnt, rc) and np.array_equal(lab, rl)
+    # size-independent properties: labels are 0 exactly on background, cover 1..L, idempotent
+    assert np.array_equal(lab == 0, m == 0)
+    for f in range(2):
+        assert np.array_equal(np.unique(lab[f]), np.arange(cnt[f] + 1))
+    lab2, cnt2 = ops.label(lab, 4)            # any non-zero is foreground
+    assert np.array_equal(cnt2, cnt) and np.array_equal(lab2, lab)
+
+
+def test_label_4k_frame(ops, oracle):
+    rng = np.random.default_rng(77)
+    m = (rng.random((1, 2160, 3840)) < 0.3).astype(np.uint8)
+    m[0, 500:900, 1000:3000] = 1
+    lab, cnt = ops.label(m, 4)
+    rl, rc = oracle.label_batch(m, 4)
+    assert np.array_equal(cnt, rc) and np.array_equal(lab, rl)
+
+
+# ------------------------------------------------------------------ stats / largest region
+def test_region_stats_and_moments(ops, oracle, golden):
+    for name in [str(n) for n in golden["mask_names"]]:
+        lab = golden["labels4_" + name]
+        cnt = int(golden["count4_" + name])
+        st = ops.region_stats(lab, max(cnt, 1))
+        assert np.array_equal(st[:cnt, :14], oracle.region_stats(lab, cnt)[:, :14]), name
+        assert np.array_equal(st[:cnt, 0], golden["areas4_" + name])
+        assert np.array_equal(st[:cnt, :10], golden["lmoments4_" + name])
+    rng = np.random.default_rng(51)
+    m = (rng.random((2, 150, 517)) < 0.55).astype(np.uint8)
+    lab, cnt = ops.label(m, 8)
+    st = ops.region_stats(lab, int(cnt.max()))
+    for f in range(2):
+        assert np.array_equal(st[f, :cnt[f], :14], oracle.region_stats(lab[f], int(cnt[f]))[:, :14])
+
+
+def test_largest_region_and_regionprops(ops, oracle, golden):
+    from video.analysis import image, regions
+    for name in [str(n) for n in golden["mask_names"]]:
+        m = golden["mask_" + name]
+        if int(golden["count4_" + name]) == 0:
+            with pytest.raises(ValueError):
+                regions.get_largest_region(m)
+            continue
+        region, area = regions.get_largest_region(m, ret_area=True)
+        assert region.dtype == bool
+        assert np.array_equal(region.astype(np.uint8), golden["largest4_" + name]), name
+        assert area == int(golden["areas4_" + name].max())
+    assert regions.find_bounding_box(golden["mask_tie"][0:8]) == (2, 2, 6, 4)
+    with pytest.raises(IndexError):
+        regions.find_bounding_box(np.zeros((4, 4), np.uint8))
+    m = golden["mask_border_blobs"]
+    rp = image.regionprops(mask=m)
+    raw = golden["moments_border_blobs"].astype(np.float64)
+    cm = oracle.complete_moments(raw)
+    assert rp.area == raw[0]
+    assert rp.centroid == (raw[1] / raw[0], raw[2] / raw[0])
+    for k, v in zip(("mu20", "mu11", "mu02", "mu30", "mu21", "mu12", "mu03", "nu20", "nu11", "nu02",
+                     "nu30", "nu21", "nu12", "nu03"), cm):
+        assert rp.moments[k] == v, k
+    assert 0 <= rp.eccentricity <= 1 and rp.major_axis_length >= rp.minor_axis_length > 0
+
+
+# ------------------------------------------------------------------------ fused pipeline
+def _engine(**kw):
+    from video.engine import FrameEngine
+    return FrameEngine(**kw)
+
+
+def test_pipeline_golden_chain(golden):
+    clip = golden["chain_clip"]
+    eng = _engine(size=(64, 48), max_batch=16, background="mean", sigma=2.0, thresh=20,
+                  morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4)
+    out = eng.run(clip, want=("mask", "labels", "counts"))
+    assert np.array_equal(out["mask"], golden["chain_mask"])
+    assert np.array_equal(out["labels"], golden["chain_labels"])
+    assert np.array_equal(out["counts"], golden["chain_counts"])
+    state, n_seen = eng.get_background()
+    assert n_seen == 16 and np.array_equal(state, golden["chain_mean"])
+    eng.close()
+
+
+@pytest.mark.parametrize("h,w,sigma,morph", [(480, 640, 2.0, 5), (270, 480, 5.0, 5),
+                                              (101, 203, 3.0, 3), (64, 96, 5.0, 0)])
+def test_pipeline_vs_oracle_batches(oracle, h, w, sigma, morph):
+    clip = _blob_clip(12, h, w, seed=h + w, salt=0.002)
+    steps = (("dilate", "rect", morph), ("erode", "rect", morph)) if morph else ()
+    rm, rl, rc, rmean = oracle.chain_u8(clip, sigma, 20, morph_ksize=morph, connectivity=4)
+    eng = _engine(size=(w, h), max_batch=8, background="mean", sigma=sigma, thresh=20,
+                  morphology=steps, connectivity=4, max_labels=64)
+    o1 = eng.run(clip[:8], want=("mask", "labels", "counts", "stats", "filtered"))
+    o2 = eng.run(clip[8:], want=("mask", "labels", "counts"))           # state carries over
+    assert np.array_equal(np.concatenate([o1["mask"], o2["mask"]]), rm)
+    assert np.array_equal(np.concatenate([o1["labels"], o2["labels"]]), rl)
+    assert np.array_equal(np.concatenate([o1["counts"], o2["counts"]]), rc)
+    assert np.array_equal(eng.get_background()[0], rmean)
+    diff, _ = oracle.bg_mean_u8(clip[:8])
+    assert np.array_equal(o1["filtered"], oracle.gaussian_u8(diff, sigma))
+    for f in range(8):
+        c = min(int(rc[f]), 64)
+        assert np.array_equal(o1["stats"][f, :c, :14], oracle.region_stats(rl[f], int(rc[f]))[:c, :14])
+    eng.close()
+
+
+def test_pipeline_1080p_full_chain(oracle):
+    """BASELINE cfg#3 shape (2 frames checked against the oracle; properties on the rest)"""
+    clip = _blob_clip(6, 1080, 1920, seed=3, nblobs=40, salt=0.002)
+    eng = _engine(size=(1920, 1080), max_batch=6, background="mean", sigma=5.0, thresh=20,
+                  morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4)
+    out = eng.run(clip, want=("mask", "labels", "counts"))
+    rm, rl, rc, _ = oracle.chain_u8(clip[:2], 5.0, 20, morph_ksize=5, connectivity=4)
+    assert np.array_equal(out["mask"][:2], rm)
+    assert np.array_equal(out["labels"][:2], rl)
+    assert np.array_equal(out["counts"][:2], rc)
+    assert np.array_equal(out["labels"] != 0, out["mask"] != 0)
+    assert np.array_equal(out["labels"].reshape(6, -1).max(1), out["counts"])
+    eng.close()
+
+
+def test_pipeline_variants(oracle):
+    clip = _blob_clip(5, 72, 100, seed=9)
+    # no background model, 8-connectivity, open instead of close, maxval 1
+    eng = _engine(size=(100, 72), max_batch=5, sigma=2.0, thresh=110, maxval=1,
+                  morphology=(("erode", "cross", 3), ("dilate", "cross", 3)), connectivity=8)
+    out = eng.run(clip)
+    m = oracle.threshold_u8(oracle.gaussian_u8(clip, 2.0), 110, 1)
+    m = oracle.morph_u8(oracle.morph_u8(m, oracle.ERODE, oracle.CROSS, 3), oracle.DILATE, oracle.CROSS, 3)
+    rl, rc = oracle.label_batch(m, 8)
+    assert np.array_equal(out["mask"], m) and np.array_equal(out["labels"], rl)
+    assert np.array_equal(out["counts"], rc)
+    eng.close()
+    # blur only, colour frames, EMA background on float32 (cfg#5 shape family)
+    rng = np.random.default_rng(4)
+    ff = rng.random((4, 30, 44, 3), dtype=np.float32)
+    eng = _engine(size=(44, 30), channels=3, dtype=np.float32, max_batch=4, background="ema",
+                  bg_rate=0.02, sigma=3.0)
+    out = eng.run(ff, want=("filtered",))
+    d, _ = oracle.bg_ema_f32(ff, rate=0.02)
+    assert np.array_equal(out["filtered"], oracle.gaussian_f32(d, 3.0))
+    eng.close()
+    # static background
+    bg = rng.random((72, 100)) * 200
+    eng = _engine(size=(100, 72), max_batch=5, background="static", sigma=0, thresh=30)
+    eng.set_background(bg)
+    out = eng.run(clip, want=("mask",))
+    assert np.array_equal(out["mask"], oracle.threshold_u8(oracle.bg_static_u8(clip, bg), 30))
+    eng.close()
+
+
+def test_pipeline_error_paths():
+    from video import _hip
+    with pytest.raises(_hip.HipError):
+        _engine(size=(64, 48), sigma=100.0)                 # > 255 taps
+    with pytest.raises(_hip.HipError):
+        _engine(size=(64, 48), channels=3, thresh=10)       # masks need 1 channel
+    with pytest.raises(_hip.HipError):
+        _engine(size=(64, 48), connectivity=4)              # labelling needs a threshold
+    eng = _engine(size=(64, 48), max_batch=2, thresh=10, connectivity=4)
+    with pytest.raises(ValueError):
+        eng.run(np.zeros((3, 48, 64), np.uint8))
+    with pytest.raises(ValueError):
+        eng.run(np.zeros((1, 48, 65), np.uint8))
+    eng.close()
+
+
+# --------------------------------------------------------------------- drop-in filter API
+def test_filter_classes_match_fused_chain_and_oracle(oracle):
+    from video.analysis.video import measure_mean, measure_mean_std
+    from video.filters import (FilterAnalysisChain, FilterBackground, FilterBlur, FilterMorphology,
+                               FilterThreshold, FilterTimeDifference)
+    from video.io.memory import VideoMemory
+    clip = _blob_clip(10, 60, 80, seed=2, salt=0.002)
+    src = VideoMemory(clip)
+    chain = FilterMorphology(FilterThreshold(FilterBlur(FilterBackground(src), 2), 20), "close", 5)
+    frames = [np.array(f) for f in chain]
+    rm, rl, rc, _ = oracle.chain_u8(clip, 2.0, 20, morph_ksize=5, connectivity=4)
+    assert np.array_equal(np.stack(frames), rm)
+    assert np.array_equal(chain[7], rm[7]) and np.array_equal(chain[3], rm[3])   # random access
+    fused = FilterAnalysisChain(VideoMemory(clip), sigma=2.0, threshold=20, batch=4, output="labels")
+    got = []
+    counts = []
+    for f in fused:
+        got.append(np.array(f))
+        counts.append(fused.last_count)
+    assert np.array_equal(np.stack(got), rl) and counts == rc.tolist()
+    assert np.array_equal(fused[6], rl[6]) and fused.last_count == rc[6]
+    fused.close()
+    assert np.array_equal(measure_mean(src), oracle.measure_mean_numpy(clip))
+    mean, std = measure_mean_std(src)
+    rmean, rstd = oracle.measure_mean_std_numpy(clip)
+    assert np.array_equal(mean, rmean) and np.array_equal(std, rstd)
+    td = list(FilterTimeDifference(VideoMemory(clip)))
+    assert len(td) == 9
+    assert all(np.array_equal(td[k], clip[k + 1].astype(np.int16) - clip[k]) for k in range(9))

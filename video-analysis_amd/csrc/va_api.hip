@@ -1,0 +1,754 @@
+// va_api.hip -- the extern "C" surface of libvideoanalysis_hip.so (include/videoanalysis_hip.h)
+//
+// Host-side plumbing only: argument checks, scratch management, kernel sequencing for the
+// fused pipeline, lazy RCCL binding.  No exception crosses the ABI; every failure sets the
+// thread-local message returned by va_last_error().
+#include <dlfcn.h>
+#include <stdarg.h>
+
+#include <mutex>
+#include <new>
+
+#include "va_common.h"
+
+namespace va {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+
+// grow-only device scratch shared by the stand-alone entry points (stream-ordered use from one
+// stream at a time, like the reference's single-threaded pull model, video/io/base.py:207-223)
+static std::mutex g_scratch_mu;
+static void *g_scratch = nullptr;
+static size_t g_scratch_bytes = 0;
+
+static int get_scratch(size_t bytes, void **out)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (bytes > g_scratch_bytes) {
+        if (g_scratch) {
+            VA_HIP(hipDeviceSynchronize());
+            VA_HIP(hipFree(g_scratch));
+            g_scratch = nullptr;
+            g_scratch_bytes = 0;
+        }
+        size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        VA_HIP(hipMalloc(&g_scratch, want));
+        g_scratch_bytes = want;
+    }
+    *out = g_scratch;
+    return VA_OK;
+}
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) & ~(a - 1); }
+
+}  // namespace va
+
+using namespace va;
+
+struct va_pipeline {
+    va_config cfg;
+    size_t px;         // elements per frame (H*W*C)
+    size_t frame_px;   // pixels per frame (H*W)
+    int w32;
+    void *bg_state;
+    size_t bg_bytes;
+    int64_t n_seen;
+    void *diff;        // background-subtracted frames (cfg.dtype)
+    void *blur;        // blurred frames when the caller does not ask for them (generic path)
+    void *gscratch;    // generic Gaussian scratch (u16 / f32)
+    uint32_t *bits[2];
+    void *ccl_ws;
+    size_t ccl_ws_bytes;
+    int32_t *labels_scratch;
+    int32_t *counts_scratch;
+    TapsQ8 tq;
+    TapsF32 tf;
+    RowSpans se[VA_MAX_MORPH_OPS];
+    bool fused;
+    char desc[160];
+};
+
+extern "C" {
+
+// ------------------------------------------------------------------------------ runtime
+const char *va_version(void) { return "videoanalysis_hip 0.1 (gfx950)"; }
+const char *va_last_error(void) { return get_error(); }
+
+int va_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int va_init(int device)
+{
+    int n = va_device_count();
+    if (n <= 0) {
+        set_error("va_init: no HIP device visible");
+        return VA_ERR_NODEV;
+    }
+    VA_REQUIRE(device >= 0 && device < n, "va_init: device %d out of range [0,%d)", device, n);
+    VA_HIP(hipSetDevice(device));
+    VA_HIP(hipFree(nullptr));  // force context creation
+    return VA_OK;
+}
+
+int va_malloc(void **dev_ptr, size_t bytes)
+{
+    VA_REQUIRE(dev_ptr, "va_malloc: NULL out pointer");
+    *dev_ptr = nullptr;
+    if (bytes == 0)
+        return VA_OK;
+    VA_HIP(hipMalloc(dev_ptr, bytes));
+    return VA_OK;
+}
+int va_free(void *dev_ptr)
+{
+    if (dev_ptr)
+        VA_HIP(hipFree(dev_ptr));
+    return VA_OK;
+}
+int va_host_alloc(void **host_ptr, size_t bytes)
+{
+    VA_REQUIRE(host_ptr, "va_host_alloc: NULL out pointer");
+    *host_ptr = nullptr;
+    if (bytes == 0)
+        return VA_OK;
+    VA_HIP(hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    return VA_OK;
+}
+int va_host_free(void *host_ptr)
+{
+    if (host_ptr)
+        VA_HIP(hipHostFree(host_ptr));
+    return VA_OK;
+}
+int va_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes)
+        VA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return VA_OK;
+}
+int va_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes)
+        VA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return VA_OK;
+}
+int va_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes)
+        VA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return VA_OK;
+}
+int va_memset(void *dst, int value, size_t bytes, void *stream)
+{
+    if (bytes)
+        VA_HIP(hipMemsetAsync(dst, value, bytes, as_stream(stream)));
+    return VA_OK;
+}
+int va_stream_sync(void *stream)
+{
+    VA_HIP(hipStreamSynchronize(as_stream(stream)));
+    return VA_OK;
+}
+
+// ------------------------------------------------------------------------------ Gaussian
+int va_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps_out, int capacity)
+{
+    VA_REQUIRE(ksize_out && taps_out, "va_gauss_taps_q8: NULL argument");
+    TapsQ8 t;
+    int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
+    if (rc)
+        return rc;
+    if (t.ksize > capacity) {
+        set_error("va_gauss_taps_q8: %d taps > capacity %d", t.ksize, capacity);
+        return VA_ERR_RANGE;
+    }
+    memcpy(taps_out, t.t, sizeof(uint16_t) * t.ksize);
+    *ksize_out = t.ksize;
+    return VA_OK;
+}
+int va_gauss_taps_f32(double sigma, int *ksize_out, float *taps_out, int capacity)
+{
+    VA_REQUIRE(ksize_out && taps_out, "va_gauss_taps_f32: NULL argument");
+    TapsF32 t;
+    int rc = gauss_taps_f32(sigma, &t.ksize, t.t, kMaxTaps);
+    if (rc)
+        return rc;
+    if (t.ksize > capacity) {
+        set_error("va_gauss_taps_f32: %d taps > capacity %d", t.ksize, capacity);
+        return VA_ERR_RANGE;
+    }
+    memcpy(taps_out, t.t, sizeof(float) * t.ksize);
+    *ksize_out = t.ksize;
+    return VA_OK;
+}
+
+int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma,
+                   void *stream)
+{
+    VA_REQUIRE(src && dst && src != dst, "va_gaussian_u8: src/dst must be distinct non-NULL");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "va_gaussian_u8: bad shape (%d,%d,%d,%d)", n, h,
+               w, c);
+    TapsQ8 t;
+    int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
+    if (rc)
+        return rc;
+    if (c == 1 && gauss_fused_supported(w, h, t))
+        return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
+    void *scratch;
+    rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);
+    if (rc)
+        return rc;
+    return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch, n, h, w, c, t, as_stream(stream));
+}
+
+// test hook: force the generic two-pass implementation
+int va_gaussian_u8_generic(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
+                           double sigma, void *stream)
+{
+    VA_REQUIRE(src && dst && src != dst, "va_gaussian_u8_generic: bad pointers");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "va_gaussian_u8_generic: bad shape");
+    TapsQ8 t;
+    int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
+    if (rc)
+        return rc;
+    void *scratch;
+    rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);
+    if (rc)
+        return rc;
+    return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch, n, h, w, c, t, as_stream(stream));
+}
+
+int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, double sigma,
+                    void *stream)
+{
+    VA_REQUIRE(src && dst && src != dst, "va_gaussian_f32: src/dst must be distinct non-NULL");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "va_gaussian_f32: bad shape (%d,%d,%d,%d)", n,
+               h, w, c);
+    TapsF32 t;
+    int rc = gauss_taps_f32(sigma, &t.ksize, t.t, kMaxTaps);
+    if (rc)
+        return rc;
+    void *scratch;
+    rc = get_scratch((size_t)n * h * w * c * sizeof(float), &scratch);
+    if (rc)
+        return rc;
+    return launch_gauss_generic_f32(src, dst, (float *)scratch, n, h, w, c, t, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------ background
+int va_bg_update(int mode, int dtype, const void *frames, void *diff_out, void *state,
+                 int64_t n_seen, double rate, int n, size_t px, void *stream)
+{
+    return launch_bg(mode, dtype, frames, diff_out, state, n_seen, rate, n, px, as_stream(stream));
+}
+int va_welford_u8(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
+                  size_t px, void *stream)
+{
+    return launch_welford(frames, mean, m2, n_seen, n, px, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------ pointwise
+int va_time_difference_u8(const uint8_t *a, const uint8_t *b, int16_t *out, size_t count,
+                          void *stream)
+{
+    return launch_time_difference(a, b, out, count, as_stream(stream));
+}
+int va_threshold_u8(const uint8_t *src, uint8_t *dst, size_t count, int thresh, int maxval,
+                    void *stream)
+{
+    return launch_threshold_u8(src, dst, count, thresh, maxval, as_stream(stream));
+}
+int va_mono_mean_u8(const uint8_t *src, uint8_t *dst, size_t pixels, void *stream)
+{
+    return launch_mono_mean(src, dst, pixels, as_stream(stream));
+}
+int va_normalize_u8(const uint8_t *src, uint8_t *dst, size_t count, double fmin, double fmax,
+                    double alpha, double tmin, void *stream)
+{
+    return launch_normalize_u8(src, dst, count, fmin, fmax, alpha, tmin, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------ morphology
+int va_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op, int shape,
+                int ksize, void *stream)
+{
+    VA_REQUIRE(src && dst && src != dst, "va_morph_u8: src/dst must be distinct non-NULL");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_morph_u8: bad shape (%d,%d,%d)", n, h, w);
+    VA_REQUIRE(op == VA_MORPH_ERODE || op == VA_MORPH_DILATE, "va_morph_u8: bad op %d", op);
+    RowSpans se;
+    int rc = make_row_spans(shape, ksize, &se);
+    if (rc)
+        return rc;
+    return launch_morph_u8(src, dst, n, h, w, op, se, as_stream(stream));
+}
+
+// test hook: morphology on the bit-packed representation used inside the pipeline
+// (mask: any non-zero byte is foreground; dst gets 0 / 255)
+int va_morph_bits_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op, int shape,
+                     int ksize, void *stream)
+{
+    VA_REQUIRE(src && dst, "va_morph_bits_u8: NULL argument");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_morph_bits_u8: bad shape");
+    RowSpans se;
+    int rc = make_row_spans(shape, ksize, &se);
+    if (rc)
+        return rc;
+    size_t words = align_up((size_t)n * h * words_per_row(w) * sizeof(uint32_t));
+    void *scratch;
+    rc = get_scratch(2 * words, &scratch);
+    if (rc)
+        return rc;
+    uint32_t *b0 = (uint32_t *)scratch, *b1 = (uint32_t *)((char *)scratch + words);
+    hipStream_t st = as_stream(stream);
+    if ((rc = launch_pack_bits(src, b0, n, h, w, 0, st)))
+        return rc;
+    if ((rc = launch_morph_bits(b0, b1, n, h, w, op, se, st)))
+        return rc;
+    return launch_unpack_bits(b1, dst, n, h, w, 255, st);
+}
+
+// ------------------------------------------------------------------------------ labelling
+size_t va_label_workspace_bytes(int n, int h, int w)
+{
+    if (n <= 0 || h <= 0 || w <= 0)
+        return 256;
+    return ccl_workspace_bytes(n, h, w);
+}
+
+int va_label_i32(const uint8_t *mask, int32_t *labels, int32_t *counts, int n, int h, int w,
+                 int connectivity, void *workspace, size_t workspace_bytes, void *stream)
+{
+    VA_REQUIRE(mask && labels && counts && workspace, "va_label_i32: NULL argument");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_label_i32: bad shape (%d,%d,%d)", n, h, w);
+    VA_REQUIRE(workspace_bytes >= va_label_workspace_bytes(n, h, w),
+               "va_label_i32: workspace of %zu bytes < required %zu", workspace_bytes,
+               va_label_workspace_bytes(n, h, w));
+    if (n == 0)
+        return VA_OK;
+    hipStream_t st = as_stream(stream);
+    size_t bits_bytes = align_up((size_t)n * h * words_per_row(w) * sizeof(uint32_t));
+    uint32_t *bits = (uint32_t *)workspace;
+    int rc = launch_pack_bits(mask, bits, n, h, w, 0, st);
+    if (rc)
+        return rc;
+    return launch_ccl(bits, labels, counts, n, h, w, connectivity, (char *)workspace + bits_bytes,
+                      workspace_bytes - bits_bytes, nullptr, 0, st);
+}
+
+int va_moments_i64(const int32_t *labels, int n, int h, int w, int max_labels, int64_t *stats,
+                   void *stream)
+{
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_moments_i64: bad shape (%d,%d,%d)", n, h, w);
+    return launch_stats_from_labels(labels, n, h, w, max_labels, stats, as_stream(stream));
+}
+
+int va_largest_region(const int32_t *labels, const int32_t *counts, const int64_t *stats, int n,
+                      int h, int w, int max_labels, int32_t *largest, int64_t *largest_area,
+                      uint8_t *mask_out, void *stream)
+{
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_largest_region: bad shape (%d,%d,%d)", n, h, w);
+    return launch_largest_region(labels, counts, stats, n, h, w, max_labels, largest, largest_area,
+                                 mask_out, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------ pipeline
+static int pipeline_free(va_pipeline *p)
+{
+    void *ptrs[] = {p->bg_state, p->diff, p->blur, p->gscratch, p->bits[0], p->bits[1],
+                    p->ccl_ws,   p->labels_scratch, p->counts_scratch};
+    for (void *q : ptrs)
+        if (q)
+            (void)hipFree(q);
+    delete p;
+    return VA_OK;
+}
+
+int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
+{
+    VA_REQUIRE(cfg && out, "va_pipeline_create: NULL argument");
+    *out = nullptr;
+    VA_REQUIRE(cfg->struct_size == (int32_t)sizeof(va_config),
+               "va_pipeline_create: va_config.struct_size %d != %zu (ABI mismatch)",
+               cfg->struct_size, sizeof(va_config));
+    VA_REQUIRE(cfg->width > 0 && cfg->height > 0 && (cfg->channels == 1 || cfg->channels == 3),
+               "va_pipeline_create: bad frame format %dx%dx%d", cfg->width, cfg->height,
+               cfg->channels);
+    VA_REQUIRE(cfg->dtype == VA_U8 || cfg->dtype == VA_F32, "va_pipeline_create: bad dtype %d",
+               cfg->dtype);
+    VA_REQUIRE(cfg->max_batch > 0, "va_pipeline_create: max_batch must be > 0");
+    VA_REQUIRE(cfg->bg_mode >= VA_BG_NONE && cfg->bg_mode <= VA_BG_STATIC,
+               "va_pipeline_create: bad bg_mode %d", cfg->bg_mode);
+    VA_REQUIRE(cfg->morph_count >= 0 && cfg->morph_count <= VA_MAX_MORPH_OPS,
+               "va_pipeline_create: morph_count %d out of range", cfg->morph_count);
+    VA_REQUIRE(cfg->connectivity == 0 || cfg->connectivity == 4 || cfg->connectivity == 8,
+               "va_pipeline_create: connectivity must be 0, 4 or 8");
+    const bool masks = cfg->thresh >= 0;
+    if (cfg->dtype == VA_F32) {
+        VA_REQUIRE(!masks, "va_pipeline_create: threshold/labelling need uint8 frames");
+        VA_REQUIRE(cfg->bg_mode == VA_BG_NONE || cfg->bg_mode == VA_BG_EMA,
+                   "va_pipeline_create: float32 frames support bg_mode NONE/EMA only");
+    }
+    if (masks)
+        VA_REQUIRE(cfg->channels == 1, "va_pipeline_create: threshold/labelling need 1 channel");
+    else
+        VA_REQUIRE(cfg->morph_count == 0 && cfg->connectivity == 0,
+                   "va_pipeline_create: morphology/labelling need a threshold (thresh >= 0)");
+    VA_REQUIRE((size_t)cfg->width * cfg->height < ((size_t)1 << 31),
+               "va_pipeline_create: frame too large");
+
+    va_pipeline *p = new (std::nothrow) va_pipeline();
+    if (!p) {
+        set_error("va_pipeline_create: out of host memory");
+        return VA_ERR_NOMEM;
+    }
+    memset(p, 0, sizeof(*p));
+    p->cfg = *cfg;
+    if (p->cfg.maxval <= 0 || p->cfg.maxval > 255)
+        p->cfg.maxval = 255;
+    p->frame_px = (size_t)cfg->width * cfg->height;
+    p->px = p->frame_px * cfg->channels;
+    p->w32 = words_per_row(cfg->width);
+    const size_t esz = cfg->dtype == VA_U8 ? 1 : 4;
+    const size_t nb = (size_t)cfg->max_batch;
+    int rc = VA_OK;
+#define PIPE_TRY(expr)                    \
+    do {                                  \
+        rc = (expr);                      \
+        if (rc) {                         \
+            pipeline_free(p);             \
+            return rc;                    \
+        }                                 \
+    } while (0)
+#define PIPE_MALLOC(ptr, bytes)                                                          \
+    do {                                                                                 \
+        hipError_t _e = hipMalloc((void **)&(ptr), (bytes));                             \
+        if (_e != hipSuccess) {                                                          \
+            set_error("va_pipeline_create: hipMalloc(%zu) failed: %s", (size_t)(bytes),  \
+                      hipGetErrorString(_e));                                            \
+            pipeline_free(p);                                                            \
+            return VA_ERR_NOMEM;                                                         \
+        }                                                                                \
+    } while (0)
+
+    if (cfg->sigma > 0) {
+        if (cfg->dtype == VA_U8) {
+            PIPE_TRY(gauss_taps_q8(cfg->sigma, &p->tq.ksize, p->tq.t, kMaxTaps));
+            p->fused = cfg->channels == 1 && gauss_fused_supported(cfg->width, cfg->height, p->tq);
+        } else {
+            PIPE_TRY(gauss_taps_f32(cfg->sigma, &p->tf.ksize, p->tf.t, kMaxTaps));
+        }
+    }
+    for (int i = 0; i < cfg->morph_count; i++) {
+        if (cfg->morph_op[i] != VA_MORPH_ERODE && cfg->morph_op[i] != VA_MORPH_DILATE) {
+            set_error("va_pipeline_create: bad morph_op[%d]=%d", i, cfg->morph_op[i]);
+            pipeline_free(p);
+            return VA_ERR_INVALID;
+        }
+        PIPE_TRY(make_row_spans(cfg->morph_shape[i], cfg->morph_ksize[i], &p->se[i]));
+    }
+    if (cfg->bg_mode != VA_BG_NONE) {
+        p->bg_bytes = p->px * (cfg->bg_mode == VA_BG_EMA ? sizeof(float) : sizeof(double));
+        PIPE_MALLOC(p->bg_state, p->bg_bytes);
+        hipError_t e = hipMemset(p->bg_state, 0, p->bg_bytes);
+        if (e != hipSuccess) {
+            set_error("va_pipeline_create: hipMemset failed: %s", hipGetErrorString(e));
+            pipeline_free(p);
+            return VA_ERR_HIP;
+        }
+        PIPE_MALLOC(p->diff, nb * p->px * esz);
+    }
+    if (cfg->sigma > 0 && !p->fused) {
+        PIPE_MALLOC(p->gscratch, nb * p->px * (cfg->dtype == VA_U8 ? 2 : 4));
+        PIPE_MALLOC(p->blur, nb * p->px * esz);
+    }
+    if (masks) {
+        size_t bb = align_up(nb * cfg->height * p->w32 * sizeof(uint32_t));
+        PIPE_MALLOC(p->bits[0], bb);
+        PIPE_MALLOC(p->bits[1], bb);
+        if (cfg->connectivity) {
+            p->ccl_ws_bytes = 2 * align_up(nb * cfg->height * sizeof(int32_t));
+            PIPE_MALLOC(p->ccl_ws, p->ccl_ws_bytes);
+            PIPE_MALLOC(p->counts_scratch, align_up(nb * sizeof(int32_t)));
+        }
+    }
+    snprintf(p->desc, sizeof(p->desc), "bg=%d gauss=%s(ksize=%d) thresh=%d morph=%d ccl=%d",
+             cfg->bg_mode, cfg->sigma > 0 ? (p->fused ? "fused-lds" : "generic") : "none",
+             cfg->sigma > 0 ? (cfg->dtype == VA_U8 ? p->tq.ksize : p->tf.ksize) : 0, cfg->thresh,
+             cfg->morph_count, cfg->connectivity);
+#undef PIPE_TRY
+#undef PIPE_MALLOC
+    *out = p;
+    return VA_OK;
+}
+
+int va_pipeline_destroy(va_pipeline_t *p)
+{
+    if (!p)
+        return VA_OK;
+    (void)hipDeviceSynchronize();
+    return pipeline_free(p);
+}
+
+const char *va_pipeline_describe(const va_pipeline_t *p) { return p ? p->desc : ""; }
+
+size_t va_bg_state_bytes(const va_pipeline_t *p) { return p ? p->bg_bytes : 0; }
+
+int va_bg_get_state(va_pipeline_t *p, void *state_host, size_t bytes, int64_t *n_seen)
+{
+    VA_REQUIRE(p, "va_bg_get_state: NULL pipeline");
+    if (n_seen)
+        *n_seen = p->n_seen;
+    if (state_host) {
+        VA_REQUIRE(bytes == p->bg_bytes, "va_bg_get_state: %zu bytes given, state is %zu", bytes,
+                   p->bg_bytes);
+        if (bytes) {
+            VA_HIP(hipDeviceSynchronize());
+            VA_HIP(hipMemcpy(state_host, p->bg_state, bytes, hipMemcpyDeviceToHost));
+        }
+    }
+    return VA_OK;
+}
+
+int va_bg_set_state(va_pipeline_t *p, const void *state_host, size_t bytes, int64_t n_seen)
+{
+    VA_REQUIRE(p, "va_bg_set_state: NULL pipeline");
+    VA_REQUIRE(n_seen >= 0, "va_bg_set_state: n_seen must be >= 0");
+    if (state_host) {
+        VA_REQUIRE(bytes == p->bg_bytes, "va_bg_set_state: %zu bytes given, state is %zu", bytes,
+                   p->bg_bytes);
+        if (bytes) {
+            VA_HIP(hipDeviceSynchronize());
+            VA_HIP(hipMemcpy(p->bg_state, state_host, bytes, hipMemcpyHostToDevice));
+        }
+    } else if (p->bg_bytes) {
+        VA_HIP(hipDeviceSynchronize());
+        VA_HIP(hipMemset(p->bg_state, 0, p->bg_bytes));
+    }
+    p->n_seen = n_seen;
+    return VA_OK;
+}
+
+int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_out,
+                    uint8_t *mask_out, int32_t *labels_out, int32_t *counts_out,
+                    int64_t *stats_out, void *stream)
+{
+    VA_REQUIRE(p && frames, "va_pipeline_run: NULL argument");
+    const va_config &c = p->cfg;
+    VA_REQUIRE(n >= 0 && n <= c.max_batch, "va_pipeline_run: n=%d exceeds max_batch=%d", n,
+               c.max_batch);
+    if (n == 0)
+        return VA_OK;
+    hipStream_t st = as_stream(stream);
+    const bool masks = c.thresh >= 0;
+    VA_REQUIRE(masks || !(mask_out || labels_out || counts_out || stats_out),
+               "va_pipeline_run: mask/label outputs requested but the pipeline has no threshold");
+    VA_REQUIRE(c.connectivity || !(labels_out || counts_out || stats_out),
+               "va_pipeline_run: label outputs requested but connectivity == 0");
+    VA_REQUIRE(!stats_out || c.max_labels > 0, "va_pipeline_run: stats_out needs max_labels > 0");
+    const size_t esz = c.dtype == VA_U8 ? 1 : 4;
+    int rc;
+    const void *cur = frames;
+
+    // 1. background subtraction (temporal, in frame order)
+    if (c.bg_mode != VA_BG_NONE) {
+        rc = launch_bg(c.bg_mode, c.dtype, cur, p->diff, p->bg_state, p->n_seen, (double)c.bg_rate,
+                       n, p->px, st);
+        if (rc)
+            return rc;
+        p->n_seen += n;
+        cur = p->diff;
+    }
+
+    // 2. Gaussian blur (+ threshold + bit packing when fused)
+    bool have_bits = false;
+    if (c.sigma > 0) {
+        if (c.dtype == VA_U8 && p->fused) {
+            rc = launch_gauss_fused_u8((const uint8_t *)cur, (uint8_t *)filtered_out,
+                                       masks ? p->bits[0] : nullptr, c.thresh, n, c.height,
+                                       c.width, p->tq, st);
+            if (rc)
+                return rc;
+            have_bits = masks;
+            cur = filtered_out;  // may be NULL; not needed any more when have_bits
+        } else {
+            void *dst = filtered_out ? filtered_out : p->blur;
+            if (c.dtype == VA_U8)
+                rc = launch_gauss_generic_u8((const uint8_t *)cur, (uint8_t *)dst,
+                                             (uint16_t *)p->gscratch, n, c.height, c.width,
+                                             c.channels, p->tq, st);
+            else
+                rc = launch_gauss_generic_f32((const float *)cur, (float *)dst,
+                                              (float *)p->gscratch, n, c.height, c.width,
+                                              c.channels, p->tf, st);
+            if (rc)
+                return rc;
+            cur = dst;
+        }
+    } else if (filtered_out) {
+        VA_HIP(hipMemcpyAsync(filtered_out, cur, (size_t)n * p->px * esz, hipMemcpyDeviceToDevice,
+                              st));
+    }
+    if (!masks)
+        return VA_OK;
+
+    // 3. threshold -> bit mask
+    int b = 0;
+    if (!have_bits) {
+        rc = launch_pack_bits((const uint8_t *)cur, p->bits[0], n, c.height, c.width, c.thresh, st);
+        if (rc)
+            return rc;
+    }
+    // 4. morphology on bits
+    for (int i = 0; i < c.morph_count; i++) {
+        rc = launch_morph_bits(p->bits[b], p->bits[b ^ 1], n, c.height, c.width, c.morph_op[i],
+                               p->se[i], st);
+        if (rc)
+            return rc;
+        b ^= 1;
+    }
+    if (mask_out) {
+        rc = launch_unpack_bits(p->bits[b], mask_out, n, c.height, c.width, c.maxval, st);
+        if (rc)
+            return rc;
+    }
+    // 5. labelling (+ statistics)
+    if (c.connectivity && (labels_out || counts_out || stats_out)) {
+        int32_t *labels = labels_out;
+        if (!labels) {
+            if (!p->labels_scratch) {
+                hipError_t e = hipMalloc((void **)&p->labels_scratch,
+                                         (size_t)c.max_batch * p->frame_px * sizeof(int32_t));
+                if (e != hipSuccess) {
+                    set_error("va_pipeline_run: hipMalloc(labels scratch) failed: %s",
+                              hipGetErrorString(e));
+                    return VA_ERR_NOMEM;
+                }
+            }
+            labels = p->labels_scratch;
+        }
+        rc = launch_ccl(p->bits[b], labels, counts_out ? counts_out : p->counts_scratch, n,
+                        c.height, c.width, c.connectivity, p->ccl_ws, p->ccl_ws_bytes, stats_out,
+                        c.max_labels, st);
+        if (rc)
+            return rc;
+    }
+    return VA_OK;
+}
+
+// ------------------------------------------------------------------------------ RCCL (lazy)
+struct NcclId {
+    char internal[128];
+};
+namespace {
+struct NcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+static NcclApi g_nccl;
+
+static int nccl_load()
+{
+    if (g_nccl.handle)
+        return VA_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)))
+            break;
+    if (!h) {
+        set_error("RCCL not found: %s", dlerror());
+        return VA_ERR_NODEV;
+    }
+    g_nccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    g_nccl.CommInitRank = (int (*)(void **, int, NcclId, int))dlsym(h, "ncclCommInitRank");
+    g_nccl.AllGather =
+        (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    g_nccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_nccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_nccl.GetUniqueId || !g_nccl.CommInitRank || !g_nccl.AllGather || !g_nccl.CommDestroy) {
+        set_error("RCCL symbols missing in librccl.so");
+        dlclose(h);
+        return VA_ERR_NODEV;
+    }
+    g_nccl.handle = h;
+    return VA_OK;
+}
+#define VA_NCCL(call)                                                                       \
+    do {                                                                                    \
+        int _r = (call);                                                                    \
+        if (_r != 0) {                                                                      \
+            set_error("%s failed: %s", #call,                                               \
+                      g_nccl.GetErrorString ? g_nccl.GetErrorString(_r) : "rccl error");    \
+            return VA_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+int va_comm_unique_id(uint8_t id_out[128])
+{
+    VA_REQUIRE(id_out, "va_comm_unique_id: NULL argument");
+    int rc = nccl_load();
+    if (rc)
+        return rc;
+    NcclId id;
+    VA_NCCL(g_nccl.GetUniqueId(&id));
+    memcpy(id_out, id.internal, 128);
+    return VA_OK;
+}
+
+int va_comm_init(void **comm_out, int world_size, int rank, const uint8_t id[128])
+{
+    VA_REQUIRE(comm_out && id, "va_comm_init: NULL argument");
+    VA_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "va_comm_init: bad rank %d/%d",
+               rank, world_size);
+    int rc = nccl_load();
+    if (rc)
+        return rc;
+    NcclId nid;
+    memcpy(nid.internal, id, 128);
+    VA_NCCL(g_nccl.CommInitRank(comm_out, world_size, nid, rank));
+    return VA_OK;
+}
+
+int va_gather_counts(void *comm, const int32_t *send, int32_t *recv, int count_per_rank,
+                     void *stream)
+{
+    VA_REQUIRE(comm && send && recv && count_per_rank >= 0, "va_gather_counts: bad argument");
+    int rc = nccl_load();
+    if (rc)
+        return rc;
+    VA_NCCL(g_nccl.AllGather(send, recv, (size_t)count_per_rank, /*ncclInt32*/ 2, comm,
+                             as_stream(stream)));
+    return VA_OK;
+}
+
+int va_comm_destroy(void *comm)
+{
+    if (!comm)
+        return VA_OK;
+    int rc = nccl_load();
+    if (rc)
+        return rc;
+    VA_NCCL(g_nccl.CommDestroy(comm));
+    return VA_OK;
+}
+
+}  // extern "C"

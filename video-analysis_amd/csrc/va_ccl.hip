@@ -1,0 +1,628 @@
+// va_ccl.hip -- connected-component labelling on bit-packed masks (A7), per-label statistics
+//               (A7 areas, A8 bounding boxes, A9 spatial moments), largest region.
+//
+// replaces labels, num = ndimage.measurements.label(mask)      video/analysis/regions.py:162
+//          areas = [np.sum(labels == l) ...]; argmax            video/analysis/regions.py:165-174
+//          find_bounding_box                                   video/analysis/regions.py:113-149
+//          cv2.moments(mask.astype(np.uint8)) spatial moments  video/analysis/image.py:353
+//
+// Design (MI355X-first, not a pixel-per-thread port of a CPU two-pass labeller):
+//   * the mask is bit-packed, so a 1080p frame is 60 dwords per row; ONE WAVE OWNS ONE ROW
+//     (lane <-> dword) and finds runs of foreground with bit arithmetic (m & ~(m << 1)).
+//   * the union-find forest has one node per RUN, identified by the linear pixel index of the
+//     run's first pixel and stored sparsely in the int32 label image itself -- no extra
+//     full-size scratch, and forest traffic scales with the number of runs, not pixels.
+//   * unions are lock-free (atomicMin towards the smaller index), so a component's root is
+//     its first pixel in raster order == SciPy's numbering rule: label = 1 + number of roots
+//     with a smaller index.  Ranks come from a per-row root count + one scan per frame.
+//   * the label image is written exactly once, coalesced (16 B per lane), by the paint pass;
+//     per-label statistics are accumulated from run segments in the same pass (closed-form
+//     sums of x, x^2, x^3 per segment), never from pixels.
+// HBM traffic per frame ~= bit mask (re-read by each small pass, L2-resident) + 4 B/px labels.
+#include "va_common.h"
+
+namespace va {
+
+namespace {
+
+constexpr int kBlock = 256;            // 4 waves
+constexpr int kRowsPerBlock = kBlock / kWave;
+
+__device__ __forceinline__ int ld_agent(const int32_t *p)
+{
+    // relaxed agent-scope load: bypasses the (non-coherent) per-CU L1 so that parents written
+    // by atomics from other CUs / XCDs are observed; also stops the compiler caching it.
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// root of `a` with path halving. Parents only ever decrease (atomicMin), so a stale read is
+// still an ancestor and the walk terminates at a node with L[r] == r.
+__device__ int find_root(int32_t *L, int a)
+{
+    for (;;) {
+        int p = ld_agent(L + a);
+        if (p == a)
+            return a;
+        int gp = ld_agent(L + p);
+        if (gp == p)
+            return p;
+        atomicMin(L + a, gp);
+        a = gp;
+    }
+}
+
+// lock-free union: the larger root is linked under the smaller one
+__device__ void unite(int32_t *L, int a, int b)
+{
+    for (;;) {
+        a = find_root(L, a);
+        b = find_root(L, b);
+        if (a == b)
+            return;
+        if (a > b) {
+            int t = a;
+            a = b;
+            b = t;
+        }
+        int old = atomicMin(L + b, a);  // a < b
+        if (old == b)
+            return;  // b was a root and now hangs under a
+        b = old;     // b had been linked meanwhile: carry on with its (old) parent
+    }
+}
+
+// first pixel of the run that contains pixel x (bit x of `row` must be set)
+__device__ __forceinline__ int run_start(const uint32_t *row, int x)
+{
+    int w = x >> 5;
+    uint32_t z = ~row[w] & (0xFFFFFFFFu >> (31 - (x & 31)));  // zero bits at or below x
+    while (z == 0) {
+        if (w == 0)
+            return 0;
+        --w;
+        z = ~row[w];
+    }
+    return (w << 5) + 32 - __clz(z);
+}
+
+struct RowCtx {
+    bool valid;
+    int lane, f, y;
+    size_t row;  // f*h + y
+};
+
+__device__ __forceinline__ RowCtx row_ctx(int h, size_t total_rows)
+{
+    RowCtx c;
+    c.lane = threadIdx.x & (kWave - 1);
+    c.row = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    c.valid = c.row < total_rows;
+    size_t r = c.valid ? c.row : 0;
+    c.f = (int)(r / h);
+    c.y = (int)(r % h);
+    return c;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        int t = __shfl_up(v, o, kWave);
+        if (lane >= o)
+            v += t;
+    }
+    return v;
+}
+
+// ---- K1: every run's first pixel becomes a singleton tree ---------------------------------
+__global__ void __launch_bounds__(kBlock)
+ccl_init_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
+                int w32, size_t total_rows)
+{
+    RowCtx c = row_ctx(h, total_rows);
+    if (!c.valid)
+        return;
+    const uint32_t *row = bits + c.row * w32;
+    int32_t *L = labels + (size_t)c.f * h * w;
+    for (int wi = c.lane; wi < w32; wi += kWave) {
+        uint32_t m = row[wi];
+        uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
+        uint32_t s = m & ~((m << 1) | prev);
+        while (s) {
+            int b = __ffs(s) - 1;
+            s &= s - 1;
+            int idx = c.y * w + (wi << 5) + b;
+            L[idx] = idx;
+        }
+    }
+}
+
+// ---- K2: link runs of row y with runs of row y-1 --------------------------------------------
+template <bool CONN8>
+__global__ void __launch_bounds__(kBlock)
+ccl_link_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
+                int w32, size_t total_rows)
+{
+    RowCtx c = row_ctx(h, total_rows);
+    if (!c.valid || c.y == 0)
+        return;
+    const uint32_t *row = bits + c.row * w32;
+    const uint32_t *up = row - w32;
+    int32_t *L = labels + (size_t)c.f * h * w;
+    const int base = c.y * w, ubase = (c.y - 1) * w;
+    for (int wi = c.lane; wi < w32; wi += kWave) {
+        const uint32_t m = row[wi], u = up[wi];
+        const uint32_t mp = wi > 0 ? row[wi - 1] : 0u, upv = wi > 0 ? up[wi - 1] : 0u;
+        // vertical contacts: one union per maximal run of (m & u)
+        uint32_t v = m & u;
+        uint32_t vs = v & ~((v << 1) | ((mp & upv) >> 31));
+        while (vs) {
+            int b = __ffs(vs) - 1;
+            vs &= vs - 1;
+            int x = (wi << 5) + b;
+            unite(L, base + run_start(row, x), ubase + run_start(up, x));
+        }
+        if (CONN8) {
+            const uint32_t mn = wi + 1 < w32 ? row[wi + 1] : 0u, un = wi + 1 < w32 ? up[wi + 1] : 0u;
+            // (y,x) ~ (y-1,x+1), needed only if neither (y-1,x) nor (y,x+1) is set
+            uint32_t uR = (u >> 1) | (un << 31), mR = (m >> 1) | (mn << 31);
+            uint32_t dr = m & uR & ~u & ~mR;
+            while (dr) {
+                int b = __ffs(dr) - 1;
+                dr &= dr - 1;
+                int x = (wi << 5) + b;
+                // (y-1,x) is background, so (y-1,x+1) starts a run
+                unite(L, base + run_start(row, x), ubase + x + 1);
+            }
+            // (y,x) ~ (y-1,x-1), needed only if neither (y-1,x) nor (y,x-1) is set
+            uint32_t uL = (u << 1) | (upv >> 31), mL = (m << 1) | (mp >> 31);
+            uint32_t dl = m & uL & ~u & ~mL;
+            while (dl) {
+                int b = __ffs(dl) - 1;
+                dl &= dl - 1;
+                int x = (wi << 5) + b;
+                // (y,x-1) is background, so (y,x) starts a run
+                unite(L, base + x, ubase + run_start(up, x - 1));
+            }
+        }
+    }
+}
+
+// ---- K3: flatten every run to its root, count roots per row ---------------------------------
+__global__ void __launch_bounds__(kBlock)
+ccl_flatten_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
+                   int32_t *__restrict__ row_cnt, int h, int w, int w32, size_t total_rows)
+{
+    RowCtx c = row_ctx(h, total_rows);
+    if (!c.valid)
+        return;
+    const uint32_t *row = bits + c.row * w32;
+    int32_t *L = labels + (size_t)c.f * h * w;
+    int cnt = 0;
+    for (int wi = c.lane; wi < w32; wi += kWave) {
+        uint32_t m = row[wi];
+        uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
+        uint32_t s = m & ~((m << 1) | prev);
+        while (s) {
+            int b = __ffs(s) - 1;
+            s &= s - 1;
+            int idx = c.y * w + (wi << 5) + b;
+            int r = find_root(L, idx);
+            if (r == idx)
+                cnt++;
+            else
+                __hip_atomic_store(L + idx, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    cnt = wave_sum(cnt);
+    if (c.lane == 0)
+        row_cnt[c.row] = cnt;
+}
+
+// ---- K4: per frame exclusive scan of the row counts ------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+ccl_rowscan_kernel(const int32_t *__restrict__ row_cnt, int32_t *__restrict__ row_off,
+                   int32_t *__restrict__ counts, int h)
+{
+    __shared__ int part[kBlock];
+    const int f = blockIdx.x, t = threadIdx.x;
+    const int32_t *cnt = row_cnt + (size_t)f * h;
+    int32_t *off = row_off + (size_t)f * h;
+    const int chunk = (h + kBlock - 1) / kBlock;
+    const int y0 = t * chunk, y1 = min(h, y0 + chunk);
+    int s = 0;
+    for (int y = y0; y < y1; y++)
+        s += cnt[y];
+    part[t] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 256 partials
+    for (int o = 1; o < kBlock; o <<= 1) {
+        int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;  // exclusive prefix of this thread's chunk
+    for (int y = y0; y < y1; y++) {
+        off[y] = run;
+        run += cnt[y];
+    }
+    if (t == kBlock - 1 && counts)
+        counts[f] = part[kBlock - 1];
+}
+
+// ---- K5: roots get their final label, stored negated ----------------------------------------
+__global__ void __launch_bounds__(kBlock)
+ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
+                const int32_t *__restrict__ row_off, int h, int w, int w32, size_t total_rows)
+{
+    RowCtx c = row_ctx(h, total_rows);
+    if (!c.valid)
+        return;
+    const uint32_t *row = bits + c.row * w32;
+    int32_t *L = labels + (size_t)c.f * h * w;
+    int base = row_off[c.row];
+    for (int w0 = 0; w0 < w32; w0 += kWave) {
+        const int wi = w0 + c.lane;
+        uint32_t roots = 0;
+        if (wi < w32) {
+            uint32_t m = row[wi];
+            uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
+            uint32_t s = m & ~((m << 1) | prev);
+            while (s) {
+                int b = __ffs(s) - 1;
+                s &= s - 1;
+                int idx = c.y * w + (wi << 5) + b;
+                if (L[idx] == idx)
+                    roots |= 1u << b;
+            }
+        }
+        const int nroots = __popc(roots);
+        const int incl = wave_incl_scan(nroots, c.lane);
+        int k = base + incl - nroots;
+        while (roots) {
+            int b = __ffs(roots) - 1;
+            roots &= roots - 1;
+            L[c.y * w + (wi << 5) + b] = -(++k);
+        }
+        base += __shfl(incl, kWave - 1, kWave);
+    }
+}
+
+// ---- K6: paint the label image (one coalesced write), optional per-label statistics ---------
+__device__ __forceinline__ void stats_add(int64_t *st, int y, int xs, int len)
+{
+    const long long xe = xs + len - 1, a = xs - 1;
+    const long long S0 = len;
+    const long long S1 = (long long)len * (xs + xe) / 2;
+    const long long S2 = xe * (xe + 1) * (2 * xe + 1) / 6 - a * (a + 1) * (2 * a + 1) / 6;
+    const long long te = xe * (xe + 1) / 2, ta = a * (a + 1) / 2;
+    const long long S3 = te * te - ta * ta;
+    const long long Y = y;
+    unsigned long long *u = reinterpret_cast<unsigned long long *>(st);
+    atomicAdd(u + 0, (unsigned long long)S0);
+    atomicAdd(u + 1, (unsigned long long)S1);
+    atomicAdd(u + 2, (unsigned long long)(Y * S0));
+    atomicAdd(u + 3, (unsigned long long)S2);
+    atomicAdd(u + 4, (unsigned long long)(Y * S1));
+    atomicAdd(u + 5, (unsigned long long)(Y * Y * S0));
+    atomicAdd(u + 6, (unsigned long long)S3);
+    atomicAdd(u + 7, (unsigned long long)(Y * S2));
+    atomicAdd(u + 8, (unsigned long long)(Y * Y * S1));
+    atomicAdd(u + 9, (unsigned long long)(Y * Y * Y * S0));
+    long long *s = reinterpret_cast<long long *>(st);
+    atomicMin(s + 10, (long long)xs);
+    atomicMin(s + 11, Y);
+    atomicMax(s + 12, xe);
+    atomicMax(s + 13, Y);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock)
+ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
+                 int w32, size_t total_rows, int64_t *__restrict__ stats, int max_labels,
+                 int vec_ok)
+{
+    __shared__ uint32_t s_m[kRowsPerBlock][kWave];
+    __shared__ uint32_t s_heads[kRowsPerBlock][kWave];
+    __shared__ int32_t s_lab[kRowsPerBlock][kWave][16];
+
+    RowCtx c = row_ctx(h, total_rows);
+    const int wv = threadIdx.x >> 6;
+    const uint32_t *row = bits + (c.valid ? c.row : 0) * w32;
+    int32_t *L = labels + (size_t)c.f * h * w;
+    int32_t *out = L + (size_t)c.y * w;
+    int64_t *fstats = STATS ? stats + (size_t)c.f * max_labels * VA_STATS_STRIDE : nullptr;
+    int carry = 0;  // label of the run that covers the last pixel of the previous chunk
+
+    for (int w0 = 0; w0 < w32; w0 += kWave) {
+        // ---- phase A: lane <-> word; label of every run (segment) inside the word
+        const int wi = w0 + c.lane;
+        uint32_t m = 0, heads = 0;
+        int last_label = 0;
+        if (c.valid && wi < w32) {
+            m = row[wi];
+            const uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
+            const uint32_t starts = m & ~((m << 1) | prev);
+            heads = starts | (m & 1u);
+            uint32_t hb = heads;
+            int k = 0;
+            while (hb) {
+                const int b = __ffs(hb) - 1;
+                hb &= hb - 1;
+                int lab;
+                if (b == 0 && prev) {
+                    // the run enters from the left: look for its first pixel inside this chunk
+                    int start = -1;
+                    for (int ww = wi - 1; ww >= w0; --ww) {
+                        uint32_t z = ~row[ww];
+                        if (z) {
+                            start = (ww << 5) + 32 - __clz(z);
+                            break;
+                        }
+                    }
+                    if (start < 0) {
+                        lab = carry;
+                    } else {
+                        int v = L[c.y * w + start];
+                        if (v >= 0)
+                            v = L[v];
+                        lab = v < 0 ? -v : v;
+                    }
+                } else {
+                    int v = L[c.y * w + (wi << 5) + b];
+                    if (v >= 0)
+                        v = L[v];  // root entry: -label, or +label if its row is already painted
+                    lab = v < 0 ? -v : v;
+                }
+                s_lab[wv][c.lane][k++] = lab;
+                last_label = lab;
+                if (STATS && lab >= 1 && lab <= max_labels) {
+                    const uint32_t seg = m >> b;
+                    const int len = (~seg) ? __ffs(~seg) - 1 : 32 - b;
+                    stats_add(fstats + (size_t)(lab - 1) * VA_STATS_STRIDE, c.y, (wi << 5) + b,
+                              len);
+                }
+            }
+        }
+        s_m[wv][c.lane] = m;
+        s_heads[wv][c.lane] = heads;
+        // label of the run covering the chunk's last pixel (lane 63's word, msb set)
+        const int lane63_label = __shfl(last_label, kWave - 1, kWave);
+        const uint32_t lane63_m = __shfl(m, kWave - 1, kWave);
+        __syncthreads();
+
+        // ---- phase B: lanes write 4 consecutive pixels each, 1 KiB per wave-instruction
+        if (c.valid) {
+            const int xbase = w0 << 5;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int p = i * 256 + c.lane * 4;
+                const int x = xbase + p;
+                if (x >= w)
+                    continue;
+                const int wl = p >> 5;
+                const uint32_t mw = s_m[wv][wl], hd = s_heads[wv][wl];
+                int v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int bit = (p & 31) + j;
+                    v[j] = 0;
+                    if ((mw >> bit) & 1u) {
+                        const int k = __popc(hd & (0xFFFFFFFFu >> (31 - bit))) - 1;
+                        v[j] = s_lab[wv][wl][k];
+                    }
+                }
+                if (vec_ok && x + 3 < w) {
+                    *reinterpret_cast<int4 *>(out + x) = make_int4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int j = 0; j < 4 && x + j < w; j++)
+                        out[x + j] = v[j];
+                }
+            }
+        }
+        carry = (lane63_m >> 31) ? lane63_label : 0;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+stats_init_kernel(int64_t *__restrict__ stats, size_t entries, int h, int w)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= entries * VA_STATS_STRIDE)
+        return;
+    int k = (int)(i % VA_STATS_STRIDE);
+    stats[i] = k == 10 ? w : k == 11 ? h : (k == 12 || k == 13) ? -1 : 0;
+}
+
+// per-label statistics from an arbitrary label image: one thread = 32 consecutive pixels,
+// equal-label segments are summed in closed form and flushed with atomics
+__global__ void __launch_bounds__(kBlock)
+stats_from_labels_kernel(const int32_t *__restrict__ labels, int h, int w, int w32,
+                         size_t total_words, int64_t *__restrict__ stats, int max_labels)
+{
+    size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= total_words)
+        return;
+    const int wi = (int)(t % w32);
+    const size_t rowi = t / w32;
+    const int y = (int)(rowi % h);
+    const int f = (int)(rowi / h);
+    const int32_t *row = labels + rowi * (size_t)w;
+    int64_t *fstats = stats + (size_t)f * max_labels * VA_STATS_STRIDE;
+    const int x0 = wi << 5, x1 = min(w, x0 + 32);
+    int cur = 0, xs = 0;
+    for (int x = x0; x <= x1; x++) {
+        int l = x < x1 ? row[x] : 0;
+        if (l != cur) {
+            if (cur >= 1 && cur <= max_labels)
+                stats_add(fstats + (size_t)(cur - 1) * VA_STATS_STRIDE, y, xs, x - xs);
+            cur = l;
+            xs = x;
+        }
+    }
+}
+
+// first maximum of the areas (np.argmax rule), one block per frame
+__global__ void __launch_bounds__(kBlock)
+largest_label_kernel(const int32_t *__restrict__ counts, const int64_t *__restrict__ stats,
+                     int max_labels, int32_t *__restrict__ largest,
+                     int64_t *__restrict__ largest_area)
+{
+    __shared__ long long s_area[kBlock];
+    __shared__ int s_lab[kBlock];
+    const int f = blockIdx.x, t = threadIdx.x;
+    int cnt = counts[f];
+    cnt = cnt > max_labels ? max_labels : cnt;
+    const int64_t *st = stats + (size_t)f * max_labels * VA_STATS_STRIDE;
+    long long best = -1;
+    int bl = 0;
+    for (int l = t; l < cnt; l += kBlock) {  // ascending l per thread: strict > keeps the first
+        long long a = st[(size_t)l * VA_STATS_STRIDE];
+        if (a > best) {
+            best = a;
+            bl = l + 1;
+        }
+    }
+    s_area[t] = best;
+    s_lab[t] = bl;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if (t < o) {
+            long long a = s_area[t + o];
+            int l = s_lab[t + o];
+            if (a > s_area[t] || (a == s_area[t] && l != 0 && (s_lab[t] == 0 || l < s_lab[t]))) {
+                s_area[t] = a;
+                s_lab[t] = l;
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        largest[f] = s_lab[0];
+        if (largest_area)
+            largest_area[f] = s_lab[0] ? s_area[0] : 0;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+select_label_kernel(const int32_t *__restrict__ labels, const int32_t *__restrict__ largest,
+                    uint8_t *__restrict__ mask, size_t frame_px, size_t total)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total)
+        return;
+    int lm = largest[i / frame_px];
+    mask[i] = (lm != 0 && labels[i] == lm) ? 1 : 0;
+}
+
+inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+size_t ccl_workspace_bytes(int n, int h, int w)
+{
+    // [bit mask for the u8 entry point][row_cnt][row_off]
+    size_t bits = (size_t)n * h * words_per_row(w) * sizeof(uint32_t);
+    size_t rows = (size_t)n * h * sizeof(int32_t);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(bits) + 2 * up(rows);
+}
+
+// workspace here = row_cnt + row_off only (the caller owns the bit mask)
+int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
+               int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
+               hipStream_t st)
+{
+    VA_REQUIRE(connectivity == 4 || connectivity == 8, "label: connectivity must be 4 or 8 (got %d)",
+               connectivity);
+    VA_REQUIRE(bits && labels && workspace, "label: NULL argument");
+    VA_REQUIRE((size_t)h * (size_t)w < ((size_t)1 << 31), "label: frame too large for int32 labels");
+    if (n == 0 || h == 0 || w == 0)
+        return VA_OK;
+    const int w32 = words_per_row(w);
+    const size_t total_rows = (size_t)n * h;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    VA_REQUIRE(ws_bytes >= 2 * up(total_rows * sizeof(int32_t)), "label: workspace too small");
+    int32_t *row_cnt = (int32_t *)workspace;
+    int32_t *row_off = (int32_t *)((char *)workspace + up(total_rows * sizeof(int32_t)));
+    const int grid = cdiv((long long)total_rows, kRowsPerBlock);
+
+    ccl_init_kernel<<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+    VA_LAUNCH_CHECK("ccl_init_kernel");
+    if (connectivity == 8)
+        ccl_link_kernel<true><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+    else
+        ccl_link_kernel<false><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+    VA_LAUNCH_CHECK("ccl_link_kernel");
+    ccl_flatten_kernel<<<grid, kBlock, 0, st>>>(bits, labels, row_cnt, h, w, w32, total_rows);
+    VA_LAUNCH_CHECK("ccl_flatten_kernel");
+    ccl_rowscan_kernel<<<n, kBlock, 0, st>>>(row_cnt, row_off, counts, h);
+    VA_LAUNCH_CHECK("ccl_rowscan_kernel");
+    ccl_rank_kernel<<<grid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, total_rows);
+    VA_LAUNCH_CHECK("ccl_rank_kernel");
+    const int vec = (w % 4 == 0) && aligned(labels, 16);
+    if (stats && max_labels > 0) {
+        size_t entries = (size_t)n * max_labels;
+        stats_init_kernel<<<cdiv((long long)entries * VA_STATS_STRIDE, kBlock), kBlock, 0, st>>>(
+            stats, entries, h, w);
+        VA_LAUNCH_CHECK("stats_init_kernel");
+        ccl_paint_kernel<true><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows, stats,
+                                                       max_labels, vec);
+    } else {
+        ccl_paint_kernel<false><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows,
+                                                        nullptr, 0, vec);
+    }
+    VA_LAUNCH_CHECK("ccl_paint_kernel");
+    return VA_OK;
+}
+
+int launch_stats_from_labels(const int32_t *labels, int n, int h, int w, int max_labels,
+                             int64_t *stats, hipStream_t st)
+{
+    VA_REQUIRE(labels && stats && max_labels > 0, "moments: NULL argument / max_labels <= 0");
+    if (n == 0 || h == 0 || w == 0)
+        return VA_OK;
+    size_t entries = (size_t)n * max_labels;
+    stats_init_kernel<<<cdiv((long long)entries * VA_STATS_STRIDE, kBlock), kBlock, 0, st>>>(
+        stats, entries, h, w);
+    VA_LAUNCH_CHECK("stats_init_kernel");
+    const int w32 = words_per_row(w);
+    size_t total_words = (size_t)n * h * w32;
+    stats_from_labels_kernel<<<cdiv((long long)total_words, kBlock), kBlock, 0, st>>>(
+        labels, h, w, w32, total_words, stats, max_labels);
+    VA_LAUNCH_CHECK("stats_from_labels_kernel");
+    return VA_OK;
+}
+
+int launch_largest_region(const int32_t *labels, const int32_t *counts, const int64_t *stats,
+                          int n, int h, int w, int max_labels, int32_t *largest,
+                          int64_t *largest_area, uint8_t *mask_out, hipStream_t st)
+{
+    VA_REQUIRE(counts && stats && largest && max_labels > 0, "largest_region: NULL argument");
+    if (n == 0)
+        return VA_OK;
+    largest_label_kernel<<<n, kBlock, 0, st>>>(counts, stats, max_labels, largest, largest_area);
+    VA_LAUNCH_CHECK("largest_label_kernel");
+    if (mask_out) {
+        VA_REQUIRE(labels, "largest_region: labels required for mask_out");
+        size_t px = (size_t)h * w, total = px * n;
+        if (total) {
+            select_label_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(labels, largest,
+                                                                                  mask_out, px, total);
+            VA_LAUNCH_CHECK("select_label_kernel");
+        }
+    }
+    return VA_OK;
+}
+
+}  // namespace va

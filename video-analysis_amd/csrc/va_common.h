@@ -1,0 +1,121 @@
+// va_common.h -- shared helpers for the HIP sources of libvideoanalysis_hip.so (gfx950 only)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/videoanalysis_hip.h"
+
+namespace va {
+
+// thread-local last-error message (va_last_error)
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *get_error();
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define VA_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            va::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__,  \
+                          __LINE__);                                                        \
+            return _e == hipErrorOutOfMemory ? VA_ERR_NOMEM : VA_ERR_HIP;                   \
+        }                                                                                   \
+    } while (0)
+
+#define VA_LAUNCH_CHECK(name)                                                               \
+    do {                                                                                    \
+        hipError_t _e = hipGetLastError();                                                  \
+        if (_e != hipSuccess) {                                                             \
+            va::set_error("launch of %s failed: %s", name, hipGetErrorString(_e));          \
+            return VA_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+#define VA_REQUIRE(cond, ...)                                                               \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            va::set_error(__VA_ARGS__);                                                     \
+            return VA_ERR_INVALID;                                                          \
+        }                                                                                   \
+    } while (0)
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline int words_per_row(int w) { return (w + 31) / 32; }
+
+// ---- host-side kernels shared between translation units --------------------------------
+// Gaussian taps (host): OpenCV's 8-bit fixed-point / float definitions. Return 0 or VA_ERR_*.
+int gauss_ksize(double sigma, bool is_u8);
+int gauss_taps_q8(double sigma, int *ksize, uint16_t *taps, int cap);
+int gauss_taps_f32(double sigma, int *ksize, float *taps, int cap);
+
+// ---- launchers (each enqueues on `stream`, returns VA_OK or an error) -------------------
+constexpr int kMaxTaps = 255;  // by-value tap tables in the kernel arguments
+struct TapsQ8 {
+    int ksize;
+    uint16_t t[kMaxTaps + 1];
+};
+struct TapsF32 {
+    int ksize;
+    float t[kMaxTaps + 1];
+};
+
+// generic (any radius / channel count) two-pass Gaussian through a u16 / f32 scratch in HBM
+int launch_gauss_generic_u8(const uint8_t *src, uint8_t *dst, uint16_t *scratch, int n, int h,
+                            int w, int c, const TapsQ8 &taps, hipStream_t st);
+int launch_gauss_generic_f32(const float *src, float *dst, float *scratch, int n, int h, int w,
+                             int c, const TapsF32 &taps, hipStream_t st);
+// fused single-channel u8 Gaussian (LDS-staged, dot4/dot2), radius <= 31; output either the
+// blurred u8 frames (dst), and/or the thresholded bit mask (bits, blurred > thresh)
+bool gauss_fused_supported(int w, int h, const TapsQ8 &taps);
+int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,
+                          int h, int w, const TapsQ8 &taps, hipStream_t st);
+
+int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, int64_t n_seen,
+              double rate, int n, size_t px, hipStream_t st);
+int launch_welford(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
+                   size_t px, hipStream_t st);
+
+int launch_threshold_u8(const uint8_t *src, uint8_t *dst, size_t count, int thresh, int maxval,
+                        hipStream_t st);
+int launch_time_difference(const uint8_t *a, const uint8_t *b, int16_t *out, size_t count,
+                           hipStream_t st);
+int launch_mono_mean(const uint8_t *src, uint8_t *dst, size_t pixels, hipStream_t st);
+int launch_normalize_u8(const uint8_t *src, uint8_t *dst, size_t count, double fmin, double fmax,
+                        double alpha, double tmin, hipStream_t st);
+
+// u8 (src > thresh) or (src != 0 when thresh < 0 ... see .hip) -> bit mask, and back
+int launch_pack_bits(const uint8_t *src, uint32_t *bits, int n, int h, int w, int thresh,
+                     hipStream_t st);
+int launch_unpack_bits(const uint32_t *bits, uint8_t *dst, int n, int h, int w, int maxval,
+                       hipStream_t st);
+
+// structuring element as per-row horizontal spans (RECT/CROSS/ELLIPSE are all row-convex)
+struct RowSpans {
+    int ksize;
+    int anchor;
+    int8_t lo[64];  // first / last+1 column (relative to the window's left edge); lo>=hi: empty
+    int8_t hi[64];
+};
+int make_row_spans(int shape, int ksize, RowSpans *out);
+int launch_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op,
+                    const RowSpans &se, hipStream_t st);
+int launch_morph_bits(const uint32_t *src, uint32_t *dst, int n, int h, int w, int op,
+                      const RowSpans &se, hipStream_t st);
+
+// connected components on bit masks; labels doubles as the union-find forest
+size_t ccl_workspace_bytes(int n, int h, int w);
+int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
+               int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
+               hipStream_t st);
+int launch_stats_from_labels(const int32_t *labels, int n, int h, int w, int max_labels,
+                             int64_t *stats, hipStream_t st);
+int launch_largest_region(const int32_t *labels, const int32_t *counts, const int64_t *stats,
+                          int n, int h, int w, int max_labels, int32_t *largest,
+                          int64_t *largest_area, uint8_t *mask_out, hipStream_t st);
+
+}  // namespace va

@@ -1,0 +1,261 @@
+// va_morph.hip -- erosion / dilation (A6) on u8 images and on bit-packed masks
+//
+// replaces cv2.erode / cv2.dilate(img, cv2.getStructuringElement(shape, (k, k)))
+//          mask_thinning, video/analysis/image.py:248-251
+// OpenCV semantics: anchor = (k/2, k/2); pixels outside the image never win (default
+// morphologyDefaultBorderValue()).  RECT / CROSS / ELLIPSE are row-convex, so an element is a
+// list of per-row column spans (RowSpans).
+//
+// The pipeline keeps masks bit-packed (32 px per dword): a 1080p mask is 259 KB instead of
+// 2 MB, horizontal neighbourhoods are shifts/ORs of three adjacent words and a 5x5 operation
+// touches 15 words per 32 output pixels.
+#include <math.h>
+
+#include "va_common.h"
+
+namespace va {
+
+int make_row_spans(int shape, int ksize, RowSpans *out)
+{
+    VA_REQUIRE(ksize >= 1, "morphology: ksize must be >= 1 (got %d)", ksize);
+    if (ksize > 63) {
+        set_error("morphology: ksize %d > 63 is not supported", ksize);
+        return VA_ERR_RANGE;
+    }
+    VA_REQUIRE(shape >= VA_SHAPE_RECT && shape <= VA_SHAPE_ELLIPSE, "morphology: bad shape %d",
+               shape);
+    out->ksize = ksize;
+    out->anchor = ksize / 2;
+    const int r = ksize / 2, c = ksize / 2;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < ksize; i++) {
+        int j1 = 0, j2 = 0;
+        if (shape == VA_SHAPE_RECT || (shape == VA_SHAPE_CROSS && i == r)) {
+            j2 = ksize;
+        } else if (shape == VA_SHAPE_CROSS) {
+            j1 = c;
+            j2 = j1 + 1;
+        } else {  // cv::getStructuringElement(MORPH_ELLIPSE)
+            int dy = i - r;
+            if (abs(dy) <= r) {
+                int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));
+                j1 = c - dx > 0 ? c - dx : 0;
+                j2 = c + dx + 1 < ksize ? c + dx + 1 : ksize;
+            }
+        }
+        out->lo[i] = (int8_t)j1;
+        out->hi[i] = (int8_t)j2;
+    }
+    return VA_OK;
+}
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ u8 <-> bit masks
+__global__ void __launch_bounds__(kBlock)
+pack_bits_kernel(const uint8_t *__restrict__ src, uint32_t *__restrict__ bits, int w, int w32,
+                 size_t total_words, int thresh, int vec_ok)
+{
+    size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= total_words)
+        return;
+    int wi = (int)(t % w32);
+    size_t rowi = t / w32;
+    const uint8_t *p = src + rowi * (size_t)w + (size_t)wi * 32;
+    int nvalid = w - wi * 32;
+    nvalid = nvalid > 32 ? 32 : nvalid;
+    uint32_t m = 0;
+    if (vec_ok && nvalid == 32) {
+        uint4 a = reinterpret_cast<const uint4 *>(p)[0];
+        uint4 b = reinterpret_cast<const uint4 *>(p)[1];
+        uint8_t px[32];
+        memcpy(px, &a, 16);
+        memcpy(px + 16, &b, 16);
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            m |= (uint32_t)((int)px[k] > thresh) << k;
+    } else {
+        for (int k = 0; k < nvalid; k++)
+            m |= (uint32_t)((int)p[k] > thresh) << k;
+    }
+    bits[t] = m;
+}
+
+__global__ void __launch_bounds__(kBlock)
+unpack_bits_kernel(const uint32_t *__restrict__ bits, uint8_t *__restrict__ dst, int w, int w32,
+                   size_t total_words, int maxval, int vec_ok)
+{
+    size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= total_words)
+        return;
+    int wi = (int)(t % w32);
+    size_t rowi = t / w32;
+    uint8_t *p = dst + rowi * (size_t)w + (size_t)wi * 32;
+    int nvalid = w - wi * 32;
+    nvalid = nvalid > 32 ? 32 : nvalid;
+    uint32_t m = bits[t];
+    if (vec_ok && nvalid == 32) {
+        uint8_t px[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            px[k] = (m >> k) & 1u ? (uint8_t)maxval : (uint8_t)0;
+        uint4 a, b;
+        memcpy(&a, px, 16);
+        memcpy(&b, px + 16, 16);
+        reinterpret_cast<uint4 *>(p)[0] = a;
+        reinterpret_cast<uint4 *>(p)[1] = b;
+    } else {
+        for (int k = 0; k < nvalid; k++)
+            p[k] = (m >> k) & 1u ? (uint8_t)maxval : (uint8_t)0;
+    }
+}
+
+// ------------------------------------------------------------------ morphology on bit masks
+// one thread = one output word (32 pixels).  ERODE = AND over the element, DILATE = OR.
+template <bool DILATE>
+__global__ void __launch_bounds__(kBlock)
+morph_bits_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int h, int w,
+                  int w32, size_t total_words, RowSpans se)
+{
+    size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= total_words)
+        return;
+    const int wi = (int)(t % w32);
+    const size_t rowi = t / w32;
+    const int y = (int)(rowi % h);
+    const uint32_t *frame = src + (rowi - y) * (size_t)w32;
+    const uint32_t border = DILATE ? 0u : 0xFFFFFFFFu;
+    const int tail = w & 31;  // valid bits in the last word (0 = all 32)
+    const uint32_t last_valid = tail ? (0xFFFFFFFFu >> (32 - tail)) : 0xFFFFFFFFu;
+    uint32_t acc = border;
+    for (int i = 0; i < se.ksize; i++) {
+        const int yy = y + i - se.anchor;
+        if (yy < 0 || yy >= h)
+            continue;
+        const int lo = se.lo[i] - se.anchor, hi = se.hi[i] - 1 - se.anchor;  // dx range
+        if (lo > hi)
+            continue;
+        const uint32_t *row = frame + (size_t)yy * w32;
+        uint32_t c = row[wi];
+        uint32_t l = wi > 0 ? row[wi - 1] : border;
+        uint32_t r = wi + 1 < w32 ? row[wi + 1] : border;
+        if (!DILATE) {  // pixels right of the image edge must not win the minimum
+            if (wi == w32 - 1)
+                c |= ~last_valid;
+            if (wi + 1 == w32 - 1)
+                r |= ~last_valid;
+        }
+        uint32_t racc = border;
+        for (int dx = lo; dx <= hi; dx++) {
+            uint32_t s;  // s[x] = src[x + dx]
+            if (dx == 0)
+                s = c;
+            else if (dx > 0)
+                s = (c >> dx) | (r << (32 - dx));
+            else
+                s = (c << -dx) | (l >> (32 + dx));
+            racc = DILATE ? (racc | s) : (racc & s);
+        }
+        acc = DILATE ? (acc | racc) : (acc & racc);
+    }
+    if (wi == w32 - 1)
+        acc &= last_valid;
+    dst[t] = acc;
+}
+
+// ------------------------------------------------------------------ morphology on u8 images
+template <bool DILATE>
+__global__ void __launch_bounds__(kBlock)
+morph_u8_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w,
+                size_t total, RowSpans se)
+{
+    size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= total)
+        return;
+    const int x = (int)(e % w);
+    const size_t rowi = e / w;
+    const int y = (int)(rowi % h);
+    const uint8_t *frame = src + (rowi - y) * (size_t)w;
+    int best = DILATE ? 0 : 255;
+    for (int i = 0; i < se.ksize; i++) {
+        const int yy = y + i - se.anchor;
+        if (yy < 0 || yy >= h)
+            continue;
+        int x0 = x + se.lo[i] - se.anchor, x1 = x + se.hi[i] - 1 - se.anchor;
+        x0 = x0 < 0 ? 0 : x0;
+        x1 = x1 >= w ? w - 1 : x1;
+        const uint8_t *row = frame + (size_t)yy * w;
+        for (int xx = x0; xx <= x1; xx++) {
+            int v = row[xx];
+            best = DILATE ? (v > best ? v : best) : (v < best ? v : best);
+        }
+    }
+    dst[e] = (uint8_t)best;
+}
+
+inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+int launch_pack_bits(const uint8_t *src, uint32_t *bits, int n, int h, int w, int thresh,
+                     hipStream_t st)
+{
+    const int w32 = words_per_row(w);
+    size_t total = (size_t)n * h * w32;
+    if (total == 0)
+        return VA_OK;
+    int vec = (w % 32 == 0) && aligned(src, 16);
+    pack_bits_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(src, bits, w, w32, total,
+                                                                       thresh, vec);
+    VA_LAUNCH_CHECK("pack_bits_kernel");
+    return VA_OK;
+}
+
+int launch_unpack_bits(const uint32_t *bits, uint8_t *dst, int n, int h, int w, int maxval,
+                       hipStream_t st)
+{
+    const int w32 = words_per_row(w);
+    size_t total = (size_t)n * h * w32;
+    if (total == 0)
+        return VA_OK;
+    int vec = (w % 32 == 0) && aligned(dst, 16);
+    unpack_bits_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(bits, dst, w, w32, total,
+                                                                         maxval, vec);
+    VA_LAUNCH_CHECK("unpack_bits_kernel");
+    return VA_OK;
+}
+
+int launch_morph_bits(const uint32_t *src, uint32_t *dst, int n, int h, int w, int op,
+                      const RowSpans &se, hipStream_t st)
+{
+    const int w32 = words_per_row(w);
+    size_t total = (size_t)n * h * w32;
+    if (total == 0)
+        return VA_OK;
+    int grid = cdiv((long long)total, kBlock);
+    if (op == VA_MORPH_DILATE)
+        morph_bits_kernel<true><<<grid, kBlock, 0, st>>>(src, dst, h, w, w32, total, se);
+    else
+        morph_bits_kernel<false><<<grid, kBlock, 0, st>>>(src, dst, h, w, w32, total, se);
+    VA_LAUNCH_CHECK("morph_bits_kernel");
+    return VA_OK;
+}
+
+int launch_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op,
+                    const RowSpans &se, hipStream_t st)
+{
+    size_t total = (size_t)n * h * w;
+    if (total == 0)
+        return VA_OK;
+    int grid = cdiv((long long)total, kBlock);
+    if (op == VA_MORPH_DILATE)
+        morph_u8_kernel<true><<<grid, kBlock, 0, st>>>(src, dst, h, w, total, se);
+    else
+        morph_u8_kernel<false><<<grid, kBlock, 0, st>>>(src, dst, h, w, total, se);
+    VA_LAUNCH_CHECK("morph_u8_kernel");
+    return VA_OK;
+}
+
+}  // namespace va

@@ -1,0 +1,431 @@
+// va_point.hip -- temporal background models and pointwise filters (HBM-streaming kernels)
+//
+// A2 measure_mean / measure_mean_std (video/analysis/video.py:26-55) + BUILD-DEFINED
+//    FilterBackground; A3 FilterTimeDifference (video/filters.py:564-568); A4 FilterThreshold;
+//    A5 FilterMonochrome / FilterNormalize (video/filters.py:101-135, 359-374).
+//
+// All of these are one-touch streams: every input byte is read once with 8-16 B per lane and
+// every output byte written once.  The background recurrence is sequential in time and
+// parallel over pixels, so one thread owns 8 consecutive pixels, keeps their float64 state in
+// registers and walks the frames of the batch in order (state is read and written once per
+// batch, not once per frame).  Built with -ffp-contract=off: the float64 expression
+// mean*n/(n+1) + frame/(n+1) is evaluated with exactly NumPy's roundings (no fma).
+#include "va_common.h"
+
+namespace va {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kVec = 8;  // pixels per thread in the vector path (one 8-byte load per frame)
+
+__device__ __forceinline__ uint8_t sat_u8_trunc(double d)
+{
+    d = d > 255.0 ? 255.0 : d;
+    return (uint8_t)(int)d;  // d >= 0: C truncation == trunc()
+}
+
+// ---- cumulative mean, float64 state ------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+bg_mean_u8_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff,
+                  double *__restrict__ mean, long long n_seen, int n, size_t px)
+{
+    size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    if (i0 >= px)
+        return;
+    double m[V];
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        m[k] = mean[i0 + k];
+    for (int f = 0; f < n; f++) {
+        uint8_t p[V];
+        if (V == 8) {
+            uint2 v = *reinterpret_cast<const uint2 *>(frames + (size_t)f * px + i0);
+            memcpy(p, &v, 8);
+        } else {
+            p[0] = frames[(size_t)f * px + i0];
+        }
+        const double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
+        uint8_t o[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double fr = (double)p[k];
+            o[k] = sat_u8_trunc(fabs(fr - m[k]));
+            m[k] = m[k] * dn / dn1 + fr / dn1;
+        }
+        if (diff) {
+            if (V == 8) {
+                uint2 v;
+                memcpy(&v, o, 8);
+                *reinterpret_cast<uint2 *>(diff + (size_t)f * px + i0) = v;
+            } else {
+                diff[(size_t)f * px + i0] = o[0];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        mean[i0 + k] = m[k];
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+bg_static_u8_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff,
+                    const double *__restrict__ bg, int n, size_t px)
+{
+    size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    if (i0 >= px)
+        return;
+    double m[V];
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        m[k] = bg[i0 + k];
+    for (int f = 0; f < n; f++) {
+        uint8_t p[V], o[V];
+        if (V == 8) {
+            uint2 v = *reinterpret_cast<const uint2 *>(frames + (size_t)f * px + i0);
+            memcpy(p, &v, 8);
+        } else {
+            p[0] = frames[(size_t)f * px + i0];
+        }
+#pragma unroll
+        for (int k = 0; k < V; k++)
+            o[k] = sat_u8_trunc(fabs((double)p[k] - m[k]));
+        if (V == 8) {
+            uint2 v;
+            memcpy(&v, o, 8);
+            *reinterpret_cast<uint2 *>(diff + (size_t)f * px + i0) = v;
+        } else {
+            diff[(size_t)f * px + i0] = o[0];
+        }
+    }
+}
+
+// ---- exponential moving average, float32 state -------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+bg_ema_u8_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff,
+                 float *__restrict__ bg, long long n_seen, float rate, int n, size_t px)
+{
+    size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    if (i0 >= px)
+        return;
+    float m[V];
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        m[k] = bg[i0 + k];
+    for (int f = 0; f < n; f++) {
+        uint8_t p[V], o[V];
+        if (V == 8) {
+            uint2 v = *reinterpret_cast<const uint2 *>(frames + (size_t)f * px + i0);
+            memcpy(p, &v, 8);
+        } else {
+            p[0] = frames[(size_t)f * px + i0];
+        }
+        const bool first = (n_seen + f) == 0;
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            float fr = (float)p[k];
+            if (first)
+                m[k] = fr;
+            float d = fr - m[k];
+            float a = truncf(fabsf(d));
+            o[k] = (uint8_t)(int)(a > 255.0f ? 255.0f : a);
+            float step = rate * d;
+            m[k] = m[k] + step;
+        }
+        if (diff) {
+            if (V == 8) {
+                uint2 v;
+                memcpy(&v, o, 8);
+                *reinterpret_cast<uint2 *>(diff + (size_t)f * px + i0) = v;
+            } else {
+                diff[(size_t)f * px + i0] = o[0];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        bg[i0 + k] = m[k];
+}
+
+// f32 frames: 4 pixels (16 B) per thread per frame
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+bg_ema_f32_kernel(const float *__restrict__ frames, float *__restrict__ diff,
+                  float *__restrict__ bg, long long n_seen, float rate, int n, size_t px)
+{
+    size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    if (i0 >= px)
+        return;
+    float m[V];
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        m[k] = bg[i0 + k];
+    for (int f = 0; f < n; f++) {
+        float p[V], o[V];
+        if (V == 4) {
+            float4 v = *reinterpret_cast<const float4 *>(frames + (size_t)f * px + i0);
+            p[0] = v.x, p[1] = v.y, p[2] = v.z, p[3] = v.w;
+        } else {
+            p[0] = frames[(size_t)f * px + i0];
+        }
+        const bool first = (n_seen + f) == 0;
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            if (first)
+                m[k] = p[k];
+            float d = p[k] - m[k];
+            o[k] = fabsf(d);
+            float step = rate * d;
+            m[k] = m[k] + step;
+        }
+        if (diff) {
+            if (V == 4)
+                *reinterpret_cast<float4 *>(diff + (size_t)f * px + i0) =
+                    make_float4(o[0], o[1], o[2], o[3]);
+            else
+                diff[(size_t)f * px + i0] = o[0];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        bg[i0 + k] = m[k];
+}
+
+// ---- Welford (measure_mean_std, video/analysis/video.py:48-50) ---------------------------
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+welford_u8_kernel(const uint8_t *__restrict__ frames, double *__restrict__ mean,
+                  double *__restrict__ m2, long long n_seen, int n, size_t px)
+{
+    size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    if (i0 >= px)
+        return;
+    double m[V], q[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+        m[k] = mean[i0 + k];
+        q[k] = m2[i0 + k];
+    }
+    for (int f = 0; f < n; f++) {
+        uint8_t p[V];
+        if (V == 8) {
+            uint2 v = *reinterpret_cast<const uint2 *>(frames + (size_t)f * px + i0);
+            memcpy(p, &v, 8);
+        } else {
+            p[0] = frames[(size_t)f * px + i0];
+        }
+        const double dn1 = (double)(n_seen + f + 1);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double fr = (double)p[k];
+            double delta = fr - m[k];
+            m[k] = m[k] + delta / dn1;
+            q[k] = q[k] + delta * (fr - m[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+        mean[i0 + k] = m[k];
+        m2[i0 + k] = q[k];
+    }
+}
+
+// ---- pointwise ------------------------------------------------------------------------------
+// 16 bytes per lane where the buffers allow it, scalar tail otherwise
+__global__ void __launch_bounds__(kBlock)
+threshold_u8_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t count,
+                    int thresh, int maxval, int vec_ok)
+{
+    size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 16;
+    if (i0 >= count)
+        return;
+    if (vec_ok && i0 + 16 <= count) {
+        uint4 v = *reinterpret_cast<const uint4 *>(src + i0);
+        uint8_t p[16];
+        memcpy(p, &v, 16);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            p[k] = (int)p[k] > thresh ? (uint8_t)maxval : (uint8_t)0;
+        memcpy(&v, p, 16);
+        *reinterpret_cast<uint4 *>(dst + i0) = v;
+    } else {
+        for (size_t i = i0; i < count && i < i0 + 16; i++)
+            dst[i] = (int)src[i] > thresh ? (uint8_t)maxval : (uint8_t)0;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+time_difference_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                       int16_t *__restrict__ out, size_t count, int vec_ok)
+{
+    size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 8;
+    if (i0 >= count)
+        return;
+    if (vec_ok && i0 + 8 <= count) {
+        uint2 va_ = *reinterpret_cast<const uint2 *>(a + i0);
+        uint2 vb_ = *reinterpret_cast<const uint2 *>(b + i0);
+        uint8_t pa[8], pb[8];
+        int16_t o[8];
+        memcpy(pa, &va_, 8);
+        memcpy(pb, &vb_, 8);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            o[k] = (int16_t)((int)pa[k] - (int)pb[k]);
+        uint4 vo;
+        memcpy(&vo, o, 16);
+        *reinterpret_cast<uint4 *>(out + i0) = vo;
+    } else {
+        for (size_t i = i0; i < count && i < i0 + 8; i++)
+            out[i] = (int16_t)((int)a[i] - (int)b[i]);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+mono_mean_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t pixels)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= pixels)
+        return;
+    // np.mean(axis=2): float64 sum of the 3 channels, divided by 3.0, astype(uint8) truncates
+    double s = (double)src[3 * i] + (double)src[3 * i + 1] + (double)src[3 * i + 2];
+    dst[i] = (uint8_t)(int)(s / 3.0);
+}
+
+__global__ void __launch_bounds__(kBlock)
+normalize_u8_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t count,
+                    double fmin, double fmax, double alpha, double tmin)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count)
+        return;
+    double f = (double)src[i];
+    f = f < fmin ? fmin : (f > fmax ? fmax : f);   // np.clip(frame, fmin, fmax)
+    double v = (f - fmin) * alpha + tmin;          // video/filters.py:129
+    int iv = (int)v;                               // astype: C truncation
+    dst[i] = (uint8_t)iv;                          // wraps like NumPy for out-of-range targets
+}
+
+inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, int64_t n_seen,
+              double rate, int n, size_t px, hipStream_t st)
+{
+    VA_REQUIRE(frames && state, "va_bg_update: frames/state must not be NULL");
+    VA_REQUIRE(n >= 0 && px > 0, "va_bg_update: bad sizes n=%d px=%zu", n, px);
+    if (n == 0)
+        return VA_OK;
+    if (dtype == VA_U8) {
+        const uint8_t *fr = (const uint8_t *)frames;
+        uint8_t *df = (uint8_t *)diff;
+        bool vec = (px % kVec == 0) && aligned(fr, 8) && (!df || aligned(df, 8));
+        int grid = vec ? cdiv((long long)(px / kVec), kBlock) : cdiv((long long)px, kBlock);
+        if (mode == VA_BG_MEAN) {
+            if (vec)
+                bg_mean_u8_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, n_seen, n, px);
+            else
+                bg_mean_u8_kernel<1><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, n_seen, n, px);
+        } else if (mode == VA_BG_EMA) {
+            if (vec)
+                bg_ema_u8_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (float *)state, n_seen,
+                                                            (float)rate, n, px);
+            else
+                bg_ema_u8_kernel<1><<<grid, kBlock, 0, st>>>(fr, df, (float *)state, n_seen,
+                                                            (float)rate, n, px);
+        } else if (mode == VA_BG_STATIC) {
+            VA_REQUIRE(df, "va_bg_update: static mode needs diff_out");
+            if (vec)
+                bg_static_u8_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (const double *)state, n, px);
+            else
+                bg_static_u8_kernel<1><<<grid, kBlock, 0, st>>>(fr, df, (const double *)state, n, px);
+        } else {
+            VA_REQUIRE(false, "va_bg_update: unsupported mode %d for u8 frames", mode);
+        }
+    } else if (dtype == VA_F32) {
+        VA_REQUIRE(mode == VA_BG_EMA, "va_bg_update: float32 frames support VA_BG_EMA only");
+        const float *fr = (const float *)frames;
+        float *df = (float *)diff;
+        bool vec = (px % 4 == 0) && aligned(fr, 16) && (!df || aligned(df, 16));
+        int grid = vec ? cdiv((long long)(px / 4), kBlock) : cdiv((long long)px, kBlock);
+        if (vec)
+            bg_ema_f32_kernel<4><<<grid, kBlock, 0, st>>>(fr, df, (float *)state, n_seen,
+                                                         (float)rate, n, px);
+        else
+            bg_ema_f32_kernel<1><<<grid, kBlock, 0, st>>>(fr, df, (float *)state, n_seen,
+                                                         (float)rate, n, px);
+    } else {
+        VA_REQUIRE(false, "va_bg_update: unknown dtype %d", dtype);
+    }
+    VA_LAUNCH_CHECK("bg kernel");
+    return VA_OK;
+}
+
+int launch_welford(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
+                   size_t px, hipStream_t st)
+{
+    VA_REQUIRE(frames && mean && m2, "va_welford_u8: NULL argument");
+    if (n <= 0)
+        return VA_OK;
+    bool vec = (px % kVec == 0) && aligned(frames, 8);
+    int grid = vec ? cdiv((long long)(px / kVec), kBlock) : cdiv((long long)px, kBlock);
+    if (vec)
+        welford_u8_kernel<8><<<grid, kBlock, 0, st>>>(frames, mean, m2, n_seen, n, px);
+    else
+        welford_u8_kernel<1><<<grid, kBlock, 0, st>>>(frames, mean, m2, n_seen, n, px);
+    VA_LAUNCH_CHECK("welford_u8_kernel");
+    return VA_OK;
+}
+
+int launch_threshold_u8(const uint8_t *src, uint8_t *dst, size_t count, int thresh, int maxval,
+                        hipStream_t st)
+{
+    VA_REQUIRE(src && dst, "va_threshold_u8: NULL argument");
+    if (count == 0)
+        return VA_OK;
+    int vec = aligned(src, 16) && aligned(dst, 16);
+    threshold_u8_kernel<<<cdiv((long long)cdiv((long long)count, 16), kBlock), kBlock, 0, st>>>(
+        src, dst, count, thresh, maxval, vec);
+    VA_LAUNCH_CHECK("threshold_u8_kernel");
+    return VA_OK;
+}
+
+int launch_time_difference(const uint8_t *a, const uint8_t *b, int16_t *out, size_t count,
+                           hipStream_t st)
+{
+    VA_REQUIRE(a && b && out, "va_time_difference_u8: NULL argument");
+    if (count == 0)
+        return VA_OK;
+    int vec = aligned(a, 8) && aligned(b, 8) && aligned(out, 16);
+    time_difference_kernel<<<cdiv((long long)cdiv((long long)count, 8), kBlock), kBlock, 0, st>>>(
+        a, b, out, count, vec);
+    VA_LAUNCH_CHECK("time_difference_kernel");
+    return VA_OK;
+}
+
+int launch_mono_mean(const uint8_t *src, uint8_t *dst, size_t pixels, hipStream_t st)
+{
+    VA_REQUIRE(src && dst, "va_mono_mean_u8: NULL argument");
+    if (pixels == 0)
+        return VA_OK;
+    mono_mean_kernel<<<cdiv((long long)pixels, kBlock), kBlock, 0, st>>>(src, dst, pixels);
+    VA_LAUNCH_CHECK("mono_mean_kernel");
+    return VA_OK;
+}
+
+int launch_normalize_u8(const uint8_t *src, uint8_t *dst, size_t count, double fmin, double fmax,
+                        double alpha, double tmin, hipStream_t st)
+{
+    VA_REQUIRE(src && dst, "va_normalize_u8: NULL argument");
+    if (count == 0)
+        return VA_OK;
+    normalize_u8_kernel<<<cdiv((long long)count, kBlock), kBlock, 0, st>>>(src, dst, count, fmin,
+                                                                          fmax, alpha, tmin);
+    VA_LAUNCH_CHECK("normalize_u8_kernel");
+    return VA_OK;
+}
+
+}  // namespace va

@@ -1,0 +1,109 @@
+"""Image operations: region properties from image moments, morphology, statistics.
+
+Reference: video/analysis/image.py -- set_image_border :205-210, regionprops :310-405.
+The ten spatial moments are accumulated on the GPU from run segments (exact integers); the
+central / normalised moments and the derived scalars are the reference's formulas evaluated in
+float64 on the host (a few dozen flops per region).
+"""
+import math
+
+import numpy as np
+
+_SPATIAL = ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03")
+
+
+def set_image_border(img, size=1, color=0):
+    """sets the border of an image to `color` (in place)"""
+    img[:size, :] = color
+    img[-size:, :] = color
+    img[:, :size] = color
+    img[:, -size:] = color
+
+
+def moments_from_spatial(spatial):
+    """dict with the 24 entries of cv2.moments() from the ten spatial moments, evaluated in the
+    operation order of OpenCV's completeMomentState"""
+    m = {k: float(v) for k, v in zip(_SPATIAL, spatial)}
+    cx = cy = inv_m00 = 0.0
+    if abs(m["m00"]) > 2.220446049250313e-16:
+        inv_m00 = 1.0 / m["m00"]
+        cx = m["m10"] * inv_m00
+        cy = m["m01"] * inv_m00
+    mu20 = m["m20"] - m["m10"] * cx
+    mu11 = m["m11"] - m["m10"] * cy
+    mu02 = m["m02"] - m["m01"] * cy
+    m["mu20"], m["mu11"], m["mu02"] = mu20, mu11, mu02
+    m["mu30"] = m["m30"] - cx * (3 * mu20 + cx * m["m10"])
+    mu11 += mu11
+    m["mu21"] = m["m21"] - cx * (mu11 + cx * m["m01"]) - cy * mu20
+    m["mu12"] = m["m12"] - cy * (mu11 + cy * m["m10"]) - cx * mu02
+    m["mu03"] = m["m03"] - cy * (3 * mu02 + cy * m["m01"])
+    inv_sqrt_m00 = math.sqrt(abs(inv_m00))
+    s2 = inv_m00 * inv_m00
+    s3 = s2 * inv_sqrt_m00
+    for k in ("20", "11", "02"):
+        m["nu" + k] = m["mu" + k] * s2
+    for k in ("30", "21", "12", "03"):
+        m["nu" + k] = m["mu" + k] * s3
+    return m
+
+
+def image_moments(mask):
+    """cv2.moments(mask.astype(np.uint8)) for a 0/1 mask (image.py:353)"""
+    from .. import ops
+    m = (np.asarray(mask) != 0).astype(np.int32)
+    if m.ndim != 2:
+        raise ValueError("mask must be 2-d")
+    return moments_from_spatial(ops.region_stats(m, 1)[0][:10])
+
+
+class regionprops(object):
+    """properties of a region given by a boolean mask or by precomputed moments
+    (reference :310-405; the formulas follow scikit-image, as the reference notes)"""
+
+    def __init__(self, mask=None, contour=None, moments=None):
+        if moments is not None:
+            self.moments = moments
+        elif mask is not None:
+            self.moments = image_moments(mask)
+        elif contour is not None:
+            raise NotImplementedError("contour moments are outside the GPU hot path")
+        else:
+            raise ValueError("Either the mask or the moments must be given")
+
+    @property
+    def area(self):
+        return self.moments["m00"]
+
+    @property
+    def centroid(self):
+        m = self.moments
+        return (m["m10"] / m["m00"], m["m01"] / m["m00"])
+
+    @property
+    def orientation(self):
+        m = self.moments
+        a, b, c = m["mu20"], m["mu11"], m["mu02"]
+        if a - c == 0:
+            return -math.pi / 4 if b > 0 else math.pi / 4
+        return -math.atan2(2 * b, (a - c)) / 2
+
+    @property
+    def inertia_tensor_eigvals(self):
+        m = self.moments
+        a, b, c = m["mu20"] / m["m00"], -m["mu11"] / m["m00"], m["mu02"] / m["m00"]
+        root = math.sqrt(4 * b ** 2 + (a - c) ** 2)
+        return (a + c) + root, (a + c) - root
+
+    @property
+    def eccentricity(self):
+        e1, e2 = self.inertia_tensor_eigvals
+        return 0 if e1 == 0 else math.sqrt(1 - e2 / e1)
+
+    @property
+    def major_axis_length(self):
+        return 4 * math.sqrt(self.inertia_tensor_eigvals[0])
+
+    @property
+    def minor_axis_length(self):
+        return 4 * math.sqrt(self.inertia_tensor_eigvals[1])

@@ -1,0 +1,162 @@
+"""FrameEngine -- the batched, device-resident form of the filter chain.
+
+One engine = one `va_pipeline_t`:  FilterBackground -> FilterBlur -> FilterThreshold ->
+FilterMorphology -> label/areas (get_largest_region's first half), executed for a whole batch
+of frames that already sit in HBM.  `run()` takes NumPy frames (upload + download, for the
+drop-in iterator API) and `run_device()` takes raw device pointers (e.g. torch tensors'
+``data_ptr()``), which is what bench.py and a multi-GPU driver use.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+from ._hip import DeviceBuffer, check
+
+
+class FrameEngine(object):
+
+    def __init__(self, size, channels=1, dtype=np.uint8, max_batch=64, background=None,
+                 bg_rate=0.02, sigma=0.0, thresh=None, maxval=255, morphology=(),
+                 connectivity=0, max_labels=0, device=None):
+        """size = (width, height) as everywhere in the reference (video/io/base.py:40-55).
+        background: None | 'mean' | 'ema' | 'static';  morphology: sequence of
+        (op, shape, ksize) with op in {'erode','dilate'}, shape in {'rect','cross','ellipse'}."""
+        self.width, self.height = int(size[0]), int(size[1])
+        self.channels = int(channels)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.uint8, np.float32):
+            raise TypeError("FrameEngine supports uint8 and float32 frames")
+        self.max_batch = int(max_batch)
+        self.connectivity = int(connectivity)
+        self.max_labels = int(max_labels)
+        self.has_mask = thresh is not None
+        morphology = list(morphology)
+        if len(morphology) > _hip.MAX_MORPH_OPS:
+            raise ValueError("at most %d morphology steps" % _hip.MAX_MORPH_OPS)
+
+        cfg = _hip.va_config()
+        cfg.struct_size = C.sizeof(_hip.va_config)
+        cfg.width, cfg.height, cfg.channels = self.width, self.height, self.channels
+        cfg.dtype = _hip.VA_U8 if self.dtype == np.uint8 else _hip.VA_F32
+        cfg.max_batch = self.max_batch
+        cfg.bg_mode = _hip.BG_MODES[background]
+        cfg.bg_rate = float(bg_rate)
+        cfg.sigma = float(sigma) if sigma else 0.0
+        cfg.thresh = -1 if thresh is None else int(thresh)
+        cfg.maxval = int(maxval)
+        cfg.morph_count = len(morphology)
+        for i, (op, shape, ksize) in enumerate(morphology):
+            cfg.morph_op[i] = _hip.MORPH_OPS.get(op, op)
+            cfg.morph_shape[i] = _hip.SHAPES.get(shape, shape)
+            cfg.morph_ksize[i] = int(ksize)
+        cfg.connectivity = self.connectivity
+        cfg.max_labels = self.max_labels
+        self._cfg = cfg
+        self._lib = _hip.lib(device)
+        self._handle = C.c_void_p()
+        check(self._lib.va_pipeline_create(C.byref(cfg), C.byref(self._handle)))
+        self.bg_mode = cfg.bg_mode
+        self._dev = {}      # name -> DeviceBuffer cache for run()
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def frame_shape(self):
+        return (self.height, self.width) + ((self.channels,) if self.channels > 1 else ())
+
+    @property
+    def description(self):
+        return self._lib.va_pipeline_describe(self._handle).decode()
+
+    # ------------------------------------------------------------------ device-pointer API
+    def run_device(self, frames_ptr, n, filtered_ptr=None, mask_ptr=None, labels_ptr=None,
+                   counts_ptr=None, stats_ptr=None, stream=None):
+        """enqueue the chain for `n` frames at device address `frames_ptr` (asynchronous)"""
+        check(self._lib.va_pipeline_run(self._handle, frames_ptr, int(n), filtered_ptr, mask_ptr,
+                                        labels_ptr, counts_ptr, stats_ptr, stream))
+
+    # ------------------------------------------------------------------ NumPy API
+    def _buf(self, name, nbytes):
+        b = self._dev.get(name)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = self._dev[name] = DeviceBuffer(nbytes)
+        return b
+
+    def run(self, frames, want=("mask", "labels", "counts")):
+        """frames: (n, H, W[, C]) array; returns a dict with the requested outputs among
+        'filtered', 'mask', 'labels', 'counts', 'stats'"""
+        arr = np.ascontiguousarray(frames, self.dtype)
+        if arr.shape[1:] != self.frame_shape:
+            raise ValueError("frames of shape %r do not match %r" % (arr.shape[1:], self.frame_shape))
+        n = arr.shape[0]
+        if n > self.max_batch:
+            raise ValueError("batch of %d exceeds max_batch=%d" % (n, self.max_batch))
+        want = set(want)
+        unknown = want - {"filtered", "mask", "labels", "counts", "stats"}
+        if unknown:
+            raise ValueError("unknown outputs %r" % sorted(unknown))
+        px = self.width * self.height
+        src = self._buf("src", arr.nbytes)
+        src.upload(arr)
+        ptr = {}
+        if "filtered" in want:
+            ptr["filtered"] = self._buf("filtered", arr.nbytes)
+        if "mask" in want:
+            ptr["mask"] = self._buf("mask", n * px)
+        if "labels" in want:
+            ptr["labels"] = self._buf("labels", n * px * 4)
+        if "counts" in want or "stats" in want:
+            ptr["counts"] = self._buf("counts", n * 4)
+        if "stats" in want:
+            ptr["stats"] = self._buf("stats", n * max(self.max_labels, 1) * _hip.STATS_STRIDE * 8)
+        g = lambda k: ptr[k].ptr if k in ptr else None
+        self.run_device(src.ptr, n, g("filtered"), g("mask"), g("labels"), g("counts"), g("stats"))
+        out = {}
+        if "filtered" in want:
+            out["filtered"] = ptr["filtered"].download(arr.shape, self.dtype)
+        if "mask" in want:
+            out["mask"] = ptr["mask"].download((n, self.height, self.width), np.uint8)
+        if "labels" in want:
+            out["labels"] = ptr["labels"].download((n, self.height, self.width), np.int32)
+        if "counts" in ptr:
+            out["counts"] = ptr["counts"].download((n,), np.int32)
+        if "stats" in want:
+            out["stats"] = ptr["stats"].download((n, self.max_labels, _hip.STATS_STRIDE), np.int64)
+        return out
+
+    # ------------------------------------------------------------------ background state
+    def get_background(self):
+        """(state array, n_seen) -- float64 for 'mean'/'static', float32 for 'ema'"""
+        nbytes = self._lib.va_bg_state_bytes(self._handle)
+        n_seen = C.c_int64()
+        if nbytes == 0:
+            return None, 0
+        dt = np.float32 if self.bg_mode == _hip.BG_EMA else np.float64
+        state = np.empty(self.frame_shape, dt)
+        check(self._lib.va_bg_get_state(self._handle, state.ctypes.data, state.nbytes,
+                                        C.byref(n_seen)))
+        return state, n_seen.value
+
+    def set_background(self, state, n_seen=0):
+        dt = np.float32 if self.bg_mode == _hip.BG_EMA else np.float64
+        if state is None:
+            check(self._lib.va_bg_set_state(self._handle, None, 0, int(n_seen)))
+            return
+        st = np.ascontiguousarray(state, dt).reshape(self.frame_shape)
+        check(self._lib.va_bg_set_state(self._handle, st.ctypes.data, st.nbytes, int(n_seen)))
+
+    def close(self):
+        if self._handle is not None and self._handle.value:
+            self._lib.va_pipeline_destroy(self._handle)
+            self._handle = C.c_void_p()
+        for b in self._dev.values():
+            b.free()
+        self._dev = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

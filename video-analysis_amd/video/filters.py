@@ -1,0 +1,501 @@
+"""video.filters -- lazy per-frame filters whose pixel work runs on the MI355X.
+
+API surface of the reference's video/filters.py (FilterFunction :56, FilterNormalize :76,
+FilterCrop :158, FilterMonochrome :348, FilterBlur :378, FilterDiffBase :492,
+FilterTimeDifference :542) plus the BUILD-DEFINED classes the north star names but the
+reference does not contain: FilterBackground, FilterThreshold, FilterMorphology,
+and FilterAnalysisChain, the batched fused form of the whole chain.
+
+Every filter is a `VideoFilterBase`: consumers iterate it or index it, `_process_frame` does
+the work and notifies listeners.  The compute goes through `video.ops` / `video.engine`, i.e.
+through the C ABI of libvideoanalysis_hip.so; there is no NumPy fallback.
+"""
+import logging
+
+import numpy as np
+
+from . import ops
+from .analysis.regions import rect_to_slices
+from .engine import FrameEngine
+from .io.base import VideoFilterBase
+
+logger = logging.getLogger("video")
+
+# translation dictionary for color channels (reference: video/filters.py:32-34)
+COLOR_CHANNELS = {"blue": 0, "b": 0, 0: 0,
+                  "green": 1, "g": 1, 1: 1,
+                  "red": 2, "r": 2, 2: 2}
+
+
+def get_color_range(dtype):
+    """range a colour value of `dtype` can take: integer limits, or (0, 1) for floats
+    (reference: video/filters.py:38-50)"""
+    if np.issubdtype(dtype, np.integer):
+        info = np.iinfo(dtype)
+        return info.min, info.max
+    if np.issubdtype(dtype, np.floating):
+        return 0, 1
+    raise ValueError("Unsupported data type `%r`" % dtype)
+
+
+class FilterFunction(VideoFilterBase):
+    """applies an arbitrary host callable to every frame (reference :56-72)"""
+
+    def __init__(self, source, function):
+        self._function = function
+        super(FilterFunction, self).__init__(source)
+
+    def _process_frame(self, frame):
+        return super(FilterFunction, self)._process_frame(self._function(frame))
+
+
+class FilterNormalize(VideoFilterBase):
+    """maps the colour interval [vmin, vmax] onto the full range of `dtype`
+    (reference :76-135): clip, (f - fmin)*alpha + tmin, astype.  uint8 -> uint8 on the GPU."""
+
+    def __init__(self, source, vmin=None, vmax=None, dtype=None):
+        self._fmin, self._fmax = vmin, vmax
+        self._dtype = None if dtype is None else np.dtype(dtype)
+        self._tmin = self._alpha = None
+        super(FilterNormalize, self).__init__(source)
+
+    def _process_frame(self, frame):
+        frame = np.asarray(frame)
+        if frame.dtype != np.uint8:
+            raise TypeError("FilterNormalize: only uint8 frames are supported on the GPU path")
+        if self._dtype is None:                 # learnt lazily from the first frame (:104-109)
+            self._dtype = frame.dtype
+        if self._dtype != np.uint8:
+            raise TypeError("FilterNormalize: only dtype=uint8 targets are supported")
+        if self._fmin is None:
+            self._fmin = frame.min()
+        if self._fmax is None:
+            self._fmax = frame.max()
+        if self._tmin is None:
+            self._tmin, tmax = get_color_range(self._dtype)
+            self._alpha = (tmax - self._tmin) / (float(self._fmax) - float(self._fmin))
+        out = ops.normalize(frame, self._fmin, self._fmax, self._alpha, self._tmin)
+        return super(FilterNormalize, self)._process_frame(out)
+
+
+def _check_coordinate(value, max_value):
+    """fractions in (-1, 1) scale with max_value, negatives count from the far edge, result
+    must lie in [0, max_value) (reference :139-154)"""
+    if -1 < value < 1:
+        value = int(value * max_value)
+    if value < 0:
+        value += max_value
+    if not 0 <= value < max_value:
+        raise IndexError("Coordinate %d is out of bounds [0, %d]." % (value, max_value))
+    return value
+
+
+class FilterCrop(VideoFilterBase):
+    """crops to rect=(left, top, width, height) or to a named region ('lower', 'upper',
+    'left', 'right' and combinations); optional colour-channel pick; consecutive crops
+    contract into one (reference :158-248).  A view -- no pixel work."""
+
+    def __init__(self, source, rect=None, region="", color_channel=None, size_alignment=1):
+        source_width, source_height = source.size
+        if rect is not None:
+            left = _check_coordinate(rect[0], source_width)
+            top = _check_coordinate(rect[1], source_height)
+            width = _check_coordinate(rect[2], source_width)
+            height = _check_coordinate(rect[3], source_height)
+        else:
+            region = region.lower()
+            left, top, width, height = 0, 0, source_width, source_height
+            if "left" in region:
+                width //= 2
+            elif "right" in region:
+                width //= 2
+                left = source_width - width
+            if "upper" in region:
+                height //= 2
+            elif "lower" in region:
+                height //= 2
+                top = source_height - height
+        while isinstance(source, FilterCrop):      # contract with parent crops
+            left += source.rect[0]
+            top += source.rect[1]
+            if source.color_channel is not None:
+                color_channel = source.color_channel
+            source = source._source
+        self.color_channel = COLOR_CHANNELS.get(color_channel, color_channel)
+        is_color = None if color_channel is None else False
+        if size_alignment != 1:
+            width = int(round(width / size_alignment) * size_alignment)
+            height = int(round(height / size_alignment) * size_alignment)
+        self.rect = (left, top, width, height)
+        self.slices = rect_to_slices(self.rect)
+        super(FilterCrop, self).__init__(source, size=self.rect[2:], is_color=is_color)
+
+    def _process_frame(self, frame):
+        if self.color_channel is None:
+            frame = frame[self.slices]
+        else:
+            frame = frame[self.slices[0], self.slices[1], self.color_channel]
+        return super(FilterCrop, self)._process_frame(frame)
+
+
+class FilterMonochrome(VideoFilterBase):
+    """colour -> monochrome: mode 'mean' (float64 mean of the channels, truncated) or a
+    channel name/index (reference :348-374)"""
+
+    def __init__(self, source, mode="mean"):
+        mode = mode.lower() if isinstance(mode, str) else mode
+        self.mode = COLOR_CHANNELS.get(mode, mode)
+        if self.mode != "mean" and self.mode not in (0, 1, 2):
+            raise ValueError("Unsupported conversion method to monochrome: %s" % (mode,))
+        super(FilterMonochrome, self).__init__(source, is_color=False)
+
+    def _process_frame(self, frame):
+        if self.mode == "mean":
+            if frame.dtype != np.uint8:
+                raise TypeError("FilterMonochrome(mean): only uint8 frames on the GPU path")
+            frame = ops.mono_mean(frame)
+        else:
+            frame = frame[:, :, self.mode]
+        return super(FilterMonochrome, self)._process_frame(frame)
+
+
+class FilterBlur(VideoFilterBase):
+    """Gaussian blur of standard deviation `sigma` (reference :378-392:
+    cv2.GaussianBlur(frame.astype(np.uint8), (0, 0), sigma)).  Unlike the reference
+     listeners ARE notified."""
+
+    def __init__(self, source, sigma=3):
+        self.sigma = sigma
+        super(FilterBlur, self).__init__(source)
+
+    def _process_frame(self, frame):
+        frame = np.asarray(frame).astype(np.uint8)          # C truncation/wrap like the reference
+        out = ops.gaussian_blur(frame, self.sigma, color=frame.ndim == 3)
+        return super(FilterBlur, self)._process_frame(out)
+
+
+class FilterThreshold(VideoFilterBase):
+    """BUILD-DEFINED: binary threshold `frame > threshold ? maxval : 0` on uint8 frames
+    (the reference builds such masks with NumPy comparisons, video/analysis/image.py:282-304)"""
+
+    def __init__(self, source, threshold=127, maxval=255):
+        self.threshold, self.maxval = int(threshold), int(maxval)
+        if not 0 <= self.maxval <= 255:
+            raise ValueError("maxval must be in [0, 255]")
+        super(FilterThreshold, self).__init__(source)
+
+    def _process_frame(self, frame):
+        frame = np.asarray(frame)
+        if frame.dtype != np.uint8:
+            raise TypeError("FilterThreshold expects uint8 frames")
+        return super(FilterThreshold, self)._process_frame(
+            ops.threshold(frame, self.threshold, self.maxval))
+
+
+class FilterMorphology(VideoFilterBase):
+    """BUILD-DEFINED: erode / dilate / open / close with a `ksize` x `ksize` structuring
+    element of `shape` in {'rect','cross','ellipse'} (primitive: cv2.erode/cv2.dilate as used at
+    video/analysis/image.py:248-251)"""
+
+    _SEQUENCES = {"erode": ("erode",), "dilate": ("dilate",), "open": ("erode", "dilate"),
+                  "close": ("dilate", "erode")}
+
+    def __init__(self, source, operation="close", ksize=5, shape="rect"):
+        if operation not in self._SEQUENCES:
+            raise ValueError("operation must be one of %s" % sorted(self._SEQUENCES))
+        if shape not in ("rect", "cross", "ellipse"):
+            raise ValueError("shape must be 'rect', 'cross' or 'ellipse'")
+        if int(ksize) < 1:
+            raise ValueError("ksize must be >= 1")
+        self.operation, self.ksize, self.shape = operation, int(ksize), shape
+        if source.is_color:
+            raise ValueError("FilterMorphology expects a monochrome video")
+        super(FilterMorphology, self).__init__(source)
+
+    @property
+    def steps(self):
+        return [(op, self.shape, self.ksize) for op in self._SEQUENCES[self.operation]]
+
+    def _process_frame(self, frame):
+        frame = np.asarray(frame)
+        if frame.dtype != np.uint8 or frame.ndim != 2:
+            raise TypeError("FilterMorphology expects 2-d uint8 frames")
+        for op, shape, ksize in self.steps:
+            frame = ops.morph(frame, op, shape, ksize)
+        return super(FilterMorphology, self)._process_frame(frame)
+
+
+# ======================================================================================
+# filters with temporal state
+# ======================================================================================
+
+class FilterDiffBase(VideoFilterBase):
+    """compares consecutive frames: frame k of the filter = compare(source[k+1], source[k])
+    (reference :492-538; iteration fixed to go through get_next_frame)"""
+
+    def __init__(self, source):
+        self._prev_frame = None
+        super(FilterDiffBase, self).__init__(source, frame_count=source.frame_count - 1)
+
+    def _compare_frames(self, this_frame, prev_frame):
+        raise NotImplementedError
+
+    def set_frame_pos(self, index):
+        if index < 0:
+            index += self.frame_count
+        self._source.set_frame_pos(index)
+        self._prev_frame = np.array(self._source.get_next_frame())
+        self._frame_pos = index
+
+    def get_frame_pos(self):
+        return self._frame_pos
+
+    def get_frame(self, index):
+        if index < 0:
+            index += self.frame_count
+        if not 0 <= index < self.frame_count:
+            raise IndexError("frame %d is out of range" % index)
+        out = self._compare_frames(self._source.get_frame(index + 1), self._source.get_frame(index))
+        return self._process_frame(out)
+
+    def get_next_frame(self):
+        if self._prev_frame is None:
+            self.set_frame_pos(self._frame_pos)
+        this_frame = np.array(self._source.get_next_frame())
+        out = self._compare_frames(this_frame, self._prev_frame)
+        self._prev_frame = this_frame
+        self._frame_pos += 1
+        return self._process_frame(out)
+
+
+class FilterTimeDifference(FilterDiffBase):
+    """this_frame.astype(int16) - prev_frame (reference :542-568)"""
+
+    def __init__(self, source, dtype=np.int16):
+        if dtype is not None and np.dtype(dtype) != np.int16:
+            raise TypeError("FilterTimeDifference: the GPU path computes int16 differences")
+        self._dtype = np.int16
+        super(FilterTimeDifference, self).__init__(source)
+
+    def _compare_frames(self, this_frame, prev_frame):
+        if this_frame.dtype != np.uint8 or prev_frame.dtype != np.uint8:
+            raise TypeError("FilterTimeDifference expects uint8 frames")
+        return ops.time_difference(this_frame, prev_frame)
+
+
+class _SequentialStateFilter(VideoFilterBase):
+    """helper for filters whose output at frame k depends on frames < k: sequential iteration
+    is incremental, a seek replays the history from frame 0 (state only)"""
+
+    def _reset_state(self):
+        raise NotImplementedError
+
+    def _advance_state(self, frames):
+        """fold frames in without producing output"""
+        raise NotImplementedError
+
+    def _emit(self, frame):
+        raise NotImplementedError
+
+    _needs_history = True       # False: the state does not depend on earlier frames
+
+    def _seek_state(self, index):
+        self._reset_state()
+        chunk = 32
+        for a in range(0, index if self._needs_history else 0, chunk):
+            frames = np.stack([np.asarray(self._source.get_frame(k))
+                               for k in range(a, min(index, a + chunk))])
+            self._advance_state(frames)
+        self._state_pos = index
+
+    def set_frame_pos(self, index):
+        if index < 0:
+            index += self.frame_count
+        if not 0 <= index < self.frame_count:
+            raise IndexError("Seeking to frame %d was not possible." % index)
+        if index != getattr(self, "_state_pos", None):
+            self._seek_state(index)
+        self._source.set_frame_pos(index)
+        self._frame_pos = index
+
+    def get_frame_pos(self):
+        return self._frame_pos
+
+    def get_frame(self, index):
+        if index < 0:
+            index += self.frame_count
+        if not 0 <= index < self.frame_count:
+            raise IndexError("frame %d is out of range" % index)
+        if index != getattr(self, "_state_pos", None):
+            self._seek_state(index)
+        out = self._emit(np.asarray(self._source.get_frame(index)))
+        self._state_pos = index + 1
+        self._frame_pos = index
+        return self._process_frame(out)
+
+    def get_next_frame(self):
+        if self._frame_pos != getattr(self, "_state_pos", None):
+            self._seek_state(self._frame_pos)
+            self._source.set_frame_pos(self._frame_pos)
+        out = self._emit(np.asarray(self._source.get_next_frame()))
+        self._frame_pos += 1
+        self._state_pos = self._frame_pos
+        return self._process_frame(out)
+
+
+class FilterBackground(_SequentialStateFilter):
+    """BUILD-DEFINED running background subtraction.
+
+    frame k -> sat_u8(trunc(|frame_k - bg_{k-1}|)), then the model is updated with frame k.
+    mode 'mean'  : bg = cumulative mean with measure_mean's float64 arithmetic
+                   `mean*n/(n+1) + frame/(n+1)` (video/analysis/video.py:33); bg_{-1} = 0
+    mode 'ema'   : bg += rate*(frame - bg) in float32; the first frame initialises bg
+    mode 'static': a fixed background image `background` (e.g. analysis.video.measure_mean())
+    """
+
+    def __init__(self, source, mode="mean", rate=0.02, background=None):
+        if mode not in ("mean", "ema", "static"):
+            raise ValueError("mode must be 'mean', 'ema' or 'static'")
+        if mode == "static" and background is None:
+            raise ValueError("mode='static' needs a background image")
+        self.mode, self.rate = mode, float(rate)
+        self._background = background
+        self._model = None
+        super(FilterBackground, self).__init__(source)
+
+    @property
+    def _needs_history(self):
+        return self.mode != "static"
+
+    def _frame_shape(self):
+        return self.shape[1:]
+
+    def _reset_state(self):
+        self._model = ops.BackgroundModel(self._frame_shape(), self.mode, self.rate, np.uint8,
+                                          self._background)
+
+    def _advance_state(self, frames):
+        if self.mode != "static":
+            self._model.process(frames.astype(np.uint8, copy=False), want_diff=False)
+
+    def _emit(self, frame):
+        if frame.dtype != np.uint8:
+            raise TypeError("FilterBackground expects uint8 frames")
+        return self._model.process(frame[None])[0]
+
+    @property
+    def background(self):
+        """current background model (float64 / float32 array)"""
+        if self._model is None:
+            self._reset_state()
+            self._state_pos = 0
+        return self._model.state
+
+
+class FilterAnalysisChain(_SequentialStateFilter):
+    """BUILD-DEFINED: the whole chain, fused and batched on the GPU.
+
+        FilterBackground -> FilterBlur -> FilterThreshold -> FilterMorphology -> label
+
+    Pulls `batch` frames from the source at a time, runs one `FrameEngine` pass over them and
+    hands the results out frame by frame, so it is still a lazy `VideoFilterBase` for
+    downstream code.  `output` selects what a frame of this video is: 'mask' (uint8),
+    'labels' (int32) or 'filtered' (blurred, background-subtracted uint8).  After each frame
+    `last_count` (number of objects) and, when max_labels > 0, `last_stats` are set.
+    Results are identical to chaining the individual filters.
+    """
+
+    def __init__(self, source, background="mean", rate=0.02, sigma=5.0, threshold=20,
+                 morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4,
+                 output="mask", batch=32, max_labels=0):
+        if source.is_color:
+            raise ValueError("FilterAnalysisChain expects a monochrome video")
+        if output not in ("mask", "labels", "filtered"):
+            raise ValueError("output must be 'mask', 'labels' or 'filtered'")
+        if output == "labels" and not connectivity:
+            raise ValueError("output='labels' needs connectivity 4 or 8")
+        self.output = output
+        self.batch = int(batch)
+        self._engine_args = dict(size=source.size, channels=1, dtype=np.uint8, max_batch=self.batch,
+                                 background=background, bg_rate=rate, sigma=sigma, thresh=threshold,
+                                 morphology=morphology, connectivity=connectivity,
+                                 max_labels=max_labels)
+        self._engine = None
+        self._cache = {}            # frame index -> dict of per-frame results
+        self.last_count = None
+        self.last_stats = None
+        super(FilterAnalysisChain, self).__init__(source, is_color=False)
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = FrameEngine(**self._engine_args)
+        return self._engine
+
+    @property
+    def _needs_history(self):
+        return self._engine_args["background"] in ("mean", "ema")
+
+    def _wanted(self):
+        want = {self.output}
+        if self._engine_args["connectivity"]:
+            want.add("counts")
+        if self._engine_args["max_labels"] > 0:
+            want.add("stats")
+        return want
+
+    def _reset_state(self):
+        self.engine.set_background(None, 0)
+        self._cache = {}
+
+    def _advance_state(self, frames):
+        if self._engine_args["background"] in ("mean", "ema"):
+            for a in range(0, len(frames), self.batch):
+                self.engine.run(frames[a:a + self.batch], want=())
+
+    def _run_batch(self, first):
+        last = min(self.frame_count, first + self.batch)
+        frames = np.stack([np.asarray(self._source.get_frame(k)) for k in range(first, last)])
+        if frames.dtype != np.uint8:
+            raise TypeError("FilterAnalysisChain expects uint8 frames")
+        res = self.engine.run(frames, want=self._wanted())
+        self._cache = {first + i: {k: v[i] for k, v in res.items()} for i in range(last - first)}
+        self._state_pos = last                      # the model has seen frames < last
+
+    def _result(self, index):
+        if index not in self._cache:
+            if self._engine is None or index != getattr(self, "_state_pos", None):
+                self._seek_state(index)
+            self._run_batch(index)
+        r = self._cache[index]
+        self.last_count = int(r["counts"]) if "counts" in r else None
+        self.last_stats = r.get("stats")
+        return r[self.output]
+
+    def set_frame_pos(self, index):
+        if index < 0:
+            index += self.frame_count
+        if not 0 <= index < self.frame_count:
+            raise IndexError("Seeking to frame %d was not possible." % index)
+        self._frame_pos = index
+
+    def get_frame(self, index):
+        if index < 0:
+            index += self.frame_count
+        if not 0 <= index < self.frame_count:
+            raise IndexError("frame %d is out of range" % index)
+        self._frame_pos = index
+        return self._process_frame(self._result(index))
+
+    def get_next_frame(self):
+        if self._frame_pos >= self.frame_count:
+            raise StopIteration
+        out = self._result(self._frame_pos)
+        self._frame_pos += 1
+        return self._process_frame(out)
+
+    def close(self, propagate=True):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        super(FilterAnalysisChain, self).close(propagate)

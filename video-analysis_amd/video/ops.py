@@ -1,0 +1,259 @@
+"""NumPy-in / NumPy-out wrappers over the C ABI (one upload, kernels, one download).
+
+These are the per-call building blocks behind ``video.filters`` and ``video.analysis``; the
+batched, device-resident path is :class:`video.engine.FrameEngine`.  Everything here runs on
+the GPU through ``libvideoanalysis_hip.so`` -- nothing is computed with NumPy.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+from ._hip import DeviceBuffer, check
+
+
+def _as_batch(arr, frame_ndim):
+    """returns (contiguous array, n, frame_shape, was_single)"""
+    arr = np.ascontiguousarray(arr)
+    if arr.ndim == frame_ndim:
+        return arr, 1, arr.shape, True
+    if arr.ndim == frame_ndim + 1:
+        return arr, arr.shape[0], arr.shape[1:], False
+    raise ValueError("expected %d or %d dimensions, got shape %r"
+                     % (frame_ndim, frame_ndim + 1, arr.shape))
+
+
+def _hwc(frame_shape):
+    if len(frame_shape) == 2:
+        return frame_shape[0], frame_shape[1], 1
+    if len(frame_shape) == 3:
+        return frame_shape
+    raise ValueError("frames must be (H,W) or (H,W,C), got %r" % (frame_shape,))
+
+
+def gaussian_blur(frames, sigma, color=False, implementation=None):
+    """cv2.GaussianBlur(frame, (0,0), sigma) on uint8 or float32 frames
+    (FilterBlur._process_frame, video/filters.py:388-392).
+
+    frames: (H,W), (N,H,W); with color=True (H,W,C), (N,H,W,C).
+    implementation: None (library's choice) or 'generic' (uint8 only, for cross-checks).
+    """
+    frames = np.asarray(frames)
+    if frames.dtype not in (np.uint8, np.float32):
+        raise TypeError("gaussian_blur supports uint8 and float32, got %s" % frames.dtype)
+    arr, n, fshape, single = _as_batch(frames, 3 if color else 2)
+    h, w, c = _hwc(fshape)
+    L = _hip.lib()
+    src = DeviceBuffer.from_array(arr)
+    dst = DeviceBuffer(arr.nbytes)
+    if arr.dtype == np.uint8:
+        fn = L.va_gaussian_u8_generic if implementation == "generic" else L.va_gaussian_u8
+    else:
+        fn = L.va_gaussian_f32
+    check(fn(src.ptr, dst.ptr, n, h, w, c, float(sigma), None))
+    out = dst.download(arr.shape, arr.dtype)
+    src.free()
+    dst.free()
+    return out
+
+
+class BackgroundModel(object):
+    """device-resident background state (BUILD-DEFINED FilterBackground; cumulative mean =
+    measure_mean's arithmetic, video/analysis/video.py:33)."""
+
+    def __init__(self, frame_shape, mode="mean", rate=0.02, dtype=np.uint8, background=None):
+        self.mode = _hip.BG_MODES[mode]
+        if self.mode == _hip.BG_NONE:
+            raise ValueError("mode must be 'mean', 'ema' or 'static'")
+        self.frame_shape = tuple(frame_shape)
+        self.px = int(np.prod(self.frame_shape))
+        self.rate = float(rate)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.uint8, np.float32):
+            raise TypeError("background model supports uint8 and float32 frames")
+        if self.dtype == np.float32 and self.mode != _hip.BG_EMA:
+            raise ValueError("float32 frames support mode='ema' only")
+        self.state_dtype = np.float32 if self.mode == _hip.BG_EMA else np.float64
+        self.n_seen = 0
+        init = np.zeros(self.frame_shape, self.state_dtype)
+        if background is not None:
+            init = np.ascontiguousarray(background, self.state_dtype).reshape(self.frame_shape)
+        elif self.mode == _hip.BG_STATIC:
+            raise ValueError("mode='static' needs a background image")
+        self._state = DeviceBuffer.from_array(init)
+
+    def process(self, frames, want_diff=True):
+        """fold `frames` (N, *frame_shape) in, return |frame - bg_prev| per frame"""
+        arr = np.ascontiguousarray(frames, self.dtype)
+        if arr.shape[1:] != self.frame_shape:
+            raise ValueError("frames of shape %r do not match %r" % (arr.shape[1:], self.frame_shape))
+        n = arr.shape[0]
+        src = DeviceBuffer.from_array(arr)
+        dst = DeviceBuffer(arr.nbytes) if want_diff else None
+        check(_hip.lib().va_bg_update(self.mode, _hip.VA_U8 if self.dtype == np.uint8 else _hip.VA_F32,
+                                      src.ptr, dst.ptr if dst else None, self._state.ptr,
+                                      self.n_seen, self.rate, n, self.px, None))
+        if self.mode != _hip.BG_STATIC:
+            self.n_seen += n
+        out = dst.download(arr.shape, arr.dtype) if dst else None
+        src.free()
+        if dst:
+            dst.free()
+        return out
+
+    @property
+    def state(self):
+        return self._state.download(self.frame_shape, self.state_dtype)
+
+    def set_state(self, state, n_seen):
+        self._state.upload(np.ascontiguousarray(state, self.state_dtype).reshape(self.frame_shape))
+        self.n_seen = int(n_seen)
+
+
+def welford(frames, mean=None, m2=None, n_seen=0):
+    """Welford update of measure_mean_std (video/analysis/video.py:48-50); returns (mean, M2)"""
+    arr = np.ascontiguousarray(frames, np.uint8)
+    fshape = arr.shape[1:]
+    px = int(np.prod(fshape))
+    mean = np.zeros(fshape) if mean is None else np.ascontiguousarray(mean, np.float64)
+    m2 = np.zeros(fshape) if m2 is None else np.ascontiguousarray(m2, np.float64)
+    src = DeviceBuffer.from_array(arr)
+    dm = DeviceBuffer.from_array(mean)
+    dq = DeviceBuffer.from_array(m2)
+    check(_hip.lib().va_welford_u8(src.ptr, dm.ptr, dq.ptr, int(n_seen), arr.shape[0], px, None))
+    out = dm.download(fshape, np.float64), dq.download(fshape, np.float64)
+    for b in (src, dm, dq):
+        b.free()
+    return out
+
+
+def time_difference(this_frame, prev_frame):
+    """this.astype(int16) - prev  (FilterTimeDifference, video/filters.py:564-568)"""
+    a = np.ascontiguousarray(this_frame, np.uint8)
+    b = np.ascontiguousarray(prev_frame, np.uint8)
+    if a.shape != b.shape:
+        raise ValueError("frame shapes differ")
+    da, db = DeviceBuffer.from_array(a), DeviceBuffer.from_array(b)
+    do = DeviceBuffer(a.size * 2)
+    check(_hip.lib().va_time_difference_u8(da.ptr, db.ptr, do.ptr, a.size, None))
+    out = do.download(a.shape, np.int16)
+    for x in (da, db, do):
+        x.free()
+    return out
+
+
+def _pointwise_u8(fn, arr, out_shape, *args):
+    src = DeviceBuffer.from_array(arr)
+    dst = DeviceBuffer(int(np.prod(out_shape)))
+    check(fn(src.ptr, dst.ptr, *args))
+    out = dst.download(out_shape, np.uint8)
+    src.free()
+    dst.free()
+    return out
+
+
+def threshold(frames, thresh, maxval=255):
+    """BUILD-DEFINED FilterThreshold: frames > thresh ? maxval : 0"""
+    a = np.ascontiguousarray(frames, np.uint8)
+    return _pointwise_u8(_hip.lib().va_threshold_u8, a, a.shape, a.size, int(thresh), int(maxval), None)
+
+
+def mono_mean(frames):
+    """np.mean(frame, axis=2).astype(uint8)  (FilterMonochrome, video/filters.py:365-366)"""
+    a = np.ascontiguousarray(frames, np.uint8)
+    if a.shape[-1] != 3:
+        raise ValueError("last dimension must be 3")
+    return _pointwise_u8(_hip.lib().va_mono_mean_u8, a, a.shape[:-1], a.size // 3, None)
+
+
+def normalize(frames, fmin, fmax, alpha, tmin):
+    """clip + affine + astype(uint8)  (FilterNormalize, video/filters.py:126-132)"""
+    a = np.ascontiguousarray(frames, np.uint8)
+    return _pointwise_u8(_hip.lib().va_normalize_u8, a, a.shape, a.size, float(fmin), float(fmax),
+                         float(alpha), float(tmin), None)
+
+
+def morph(frames, op, shape="rect", ksize=3, implementation=None):
+    """cv2.erode / cv2.dilate (video/analysis/image.py:248-251) on (H,W) or (N,H,W) uint8.
+    implementation='bits' runs the bit-packed kernel of the pipeline (binary masks only)."""
+    arr, n, fshape, _ = _as_batch(np.asarray(frames, np.uint8), 2)
+    h, w = fshape
+    L = _hip.lib()
+    fn = L.va_morph_bits_u8 if implementation == "bits" else L.va_morph_u8
+    return _pointwise_u8(fn, arr, arr.shape, n, h, w, _hip.MORPH_OPS.get(op, op),
+                         _hip.SHAPES.get(shape, shape), int(ksize), None)
+
+
+def label(masks, connectivity=4):
+    """ndimage.measurements.label (video/analysis/regions.py:162) for (H,W) or (N,H,W) masks.
+    returns (labels int32, counts): counts is an int for a single mask, else an int32 array"""
+    m = np.asarray(masks)
+    if m.dtype != np.uint8:
+        m = (m != 0).astype(np.uint8)
+    arr, n, fshape, single = _as_batch(m, 2)
+    h, w = fshape
+    L = _hip.lib()
+    src = DeviceBuffer.from_array(arr)
+    lab = DeviceBuffer(arr.size * 4)
+    cnt = DeviceBuffer(max(n, 1) * 4)
+    ws_bytes = L.va_label_workspace_bytes(n, h, w)
+    ws = DeviceBuffer(ws_bytes)
+    check(L.va_label_i32(src.ptr, lab.ptr, cnt.ptr, n, h, w, int(connectivity), ws.ptr, ws_bytes, None))
+    labels = lab.download(arr.shape, np.int32)
+    counts = cnt.download((n,), np.int32)
+    for b in (src, lab, cnt, ws):
+        b.free()
+    if single:
+        return labels, int(counts[0])
+    return labels, counts
+
+
+def region_stats(labels, max_labels):
+    """per-label area / raw moments / bbox: (N?, max_labels, 16) int64, see _hip.STAT_NAMES"""
+    arr, n, fshape, single = _as_batch(np.asarray(labels, np.int32), 2)
+    h, w = fshape
+    max_labels = max(int(max_labels), 1)
+    src = DeviceBuffer.from_array(arr)
+    st = DeviceBuffer(n * max_labels * _hip.STATS_STRIDE * 8)
+    check(_hip.lib().va_moments_i64(src.ptr, n, h, w, max_labels, st.ptr, None))
+    out = st.download((n, max_labels, _hip.STATS_STRIDE), np.int64)
+    src.free()
+    st.free()
+    return out[0] if single else out
+
+
+def largest_region(mask, connectivity=4):
+    """label + areas + first-max argmax + select, all on the GPU.
+    returns (mask of the largest region as bool, its area, number of regions)"""
+    m = np.asarray(mask)
+    if m.ndim != 2:
+        raise ValueError("mask must be 2-d")
+    if m.dtype != np.uint8:
+        m = (m != 0).astype(np.uint8)
+    m = np.ascontiguousarray(m)
+    h, w = m.shape
+    L = _hip.lib()
+    src = DeviceBuffer.from_array(m)
+    lab = DeviceBuffer(m.size * 4)
+    cnt = DeviceBuffer(4)
+    ws_bytes = L.va_label_workspace_bytes(1, h, w)
+    ws = DeviceBuffer(ws_bytes)
+    check(L.va_label_i32(src.ptr, lab.ptr, cnt.ptr, 1, h, w, int(connectivity), ws.ptr, ws_bytes, None))
+    count = int(cnt.download((1,), np.int32)[0])
+    bufs = [src, lab, cnt, ws]
+    try:
+        if count == 0:
+            return np.zeros(m.shape, bool), 0, 0
+        st = DeviceBuffer(count * _hip.STATS_STRIDE * 8)
+        big = DeviceBuffer(4)
+        area = DeviceBuffer(8)
+        sel = DeviceBuffer(m.size)
+        bufs += [st, big, area, sel]
+        check(L.va_moments_i64(lab.ptr, 1, h, w, count, st.ptr, None))
+        check(L.va_largest_region(lab.ptr, cnt.ptr, st.ptr, 1, h, w, count, big.ptr, area.ptr,
+                                  sel.ptr, None))
+        out = sel.download(m.shape, np.uint8).astype(bool)
+        return out, int(area.download((1,), np.int64)[0]), count
+    finally:
+        for b in bufs:
+            b.free()
