@@ -369,6 +369,8 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                             break;
                         }
                     }
+                    if (start < 0 && (w0 == 0 || (row[w0 - 1] >> 31) == 0u))
+                        start = w0 << 5;  // the run begins exactly at the chunk's first pixel
                     if (start < 0) {
                         lab = carry;
                     } else {

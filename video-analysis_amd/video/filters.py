@@ -207,14 +207,14 @@ class FilterMorphology(VideoFilterBase):
             raise ValueError("shape must be 'rect', 'cross' or 'ellipse'")
         if int(ksize) < 1:
             raise ValueError("ksize must be >= 1")
-        self.operation, self.ksize, self.shape = operation, int(ksize), shape
+        self.operation, self.ksize, self.element = operation, int(ksize), shape
         if source.is_color:
             raise ValueError("FilterMorphology expects a monochrome video")
         super(FilterMorphology, self).__init__(source)
 
     @property
     def steps(self):
-        return [(op, self.shape, self.ksize) for op in self._SEQUENCES[self.operation]]
+        return [(op, self.element, self.ksize) for op in self._SEQUENCES[self.operation]]
 
     def _process_frame(self, frame):
         frame = np.asarray(frame)
