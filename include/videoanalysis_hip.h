@@ -199,6 +199,15 @@ size_t va_bg_state_bytes(const va_pipeline_t *p);
 /* name of the implementation used for the Gaussian stage ("fused-lds" / "generic") */
 const char *va_pipeline_describe(const va_pipeline_t *p);
 
+/* per-stage device time, measured with HIP events recorded on the run's own stream (what
+ * bench.py's `roofline` object is computed from).  enable != 0 starts/reset recording; every
+ * va_pipeline_run then records one event per stage (never waits).  stage_times waits for the
+ * last event and sums, per stage name, the elapsed ms and the number of launches.
+ * names: capacity x 32 chars. */
+int va_pipeline_profile(va_pipeline_t *p, int enable);
+int va_pipeline_stage_times(va_pipeline_t *p, int capacity, char *names, double *total_ms,
+                            int32_t *launches, int *nstages_out);
+
 /* ------------------------------------------------------------------ test hooks
  * Same contracts as va_gaussian_u8 / va_morph_u8, but forcing one implementation so that the
  * parity tests can compare the generic two-pass Gaussian with the fused LDS kernel, and the

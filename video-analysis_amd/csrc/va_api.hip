@@ -75,6 +75,7 @@ struct va_pipeline {
     RowSpans se[VA_MAX_MORPH_OPS];
     bool fused;
     char desc[160];
+    StageProfiler *prof;
 };
 
 extern "C" {
@@ -373,6 +374,12 @@ static int pipeline_free(va_pipeline *p)
     for (void *q : ptrs)
         if (q)
             (void)hipFree(q);
+    if (p->prof) {
+        for (int i = 0; i < StageProfiler::kMaxMarks; i++)
+            if (p->prof->created[i])
+                (void)hipEventDestroy(p->prof->ev[i]);
+        delete p->prof;
+    }
     delete p;
     return VA_OK;
 }
@@ -562,6 +569,13 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     const size_t esz = c.dtype == VA_U8 ? 1 : 4;
     int rc;
     const void *cur = frames;
+    StageProfiler *prof = (p->prof && p->prof->enabled) ? p->prof : nullptr;
+#define VA_MARK(nm)             \
+    do {                        \
+        if (prof)               \
+            prof->mark(nm, st); \
+    } while (0)
+    VA_MARK(nullptr);
 
     // 1. background subtraction (temporal, in frame order)
     if (c.bg_mode != VA_BG_NONE) {
@@ -571,6 +585,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             return rc;
         p->n_seen += n;
         cur = p->diff;
+        VA_MARK("bg");
     }
 
     // 2. Gaussian blur (+ threshold + bit packing when fused)
@@ -584,6 +599,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
                 return rc;
             have_bits = masks;
             cur = filtered_out;  // may be NULL; not needed any more when have_bits
+            VA_MARK("gauss_fused");
         } else {
             void *dst = filtered_out ? filtered_out : p->blur;
             if (c.dtype == VA_U8)
@@ -597,6 +613,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             if (rc)
                 return rc;
             cur = dst;
+            VA_MARK("gauss_generic");
         }
     } else if (filtered_out) {
         VA_HIP(hipMemcpyAsync(filtered_out, cur, (size_t)n * p->px * esz, hipMemcpyDeviceToDevice,
@@ -611,6 +628,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
         rc = launch_pack_bits((const uint8_t *)cur, p->bits[0], n, c.height, c.width, c.thresh, st);
         if (rc)
             return rc;
+        VA_MARK("threshold_pack");
     }
     // 4. morphology on bits
     for (int i = 0; i < c.morph_count; i++) {
@@ -619,11 +637,13 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
         if (rc)
             return rc;
         b ^= 1;
+        VA_MARK(c.morph_op[i] == VA_MORPH_DILATE ? "morph_dilate" : "morph_erode");
     }
     if (mask_out) {
         rc = launch_unpack_bits(p->bits[b], mask_out, n, c.height, c.width, c.maxval, st);
         if (rc)
             return rc;
+        VA_MARK("mask_unpack");
     }
     // 5. labelling (+ statistics)
     if (c.connectivity && (labels_out || counts_out || stats_out)) {
@@ -642,10 +662,63 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
         }
         rc = launch_ccl(p->bits[b], labels, counts_out ? counts_out : p->counts_scratch, n,
                         c.height, c.width, c.connectivity, p->ccl_ws, p->ccl_ws_bytes, stats_out,
-                        c.max_labels, st);
+                        c.max_labels, st, prof);
         if (rc)
             return rc;
     }
+#undef VA_MARK
+    return VA_OK;
+}
+
+int va_pipeline_profile(va_pipeline_t *p, int enable)
+{
+    VA_REQUIRE(p, "va_pipeline_profile: NULL pipeline");
+    if (!p->prof) {
+        p->prof = new (std::nothrow) StageProfiler();
+        if (!p->prof) {
+            set_error("va_pipeline_profile: out of host memory");
+            return VA_ERR_NOMEM;
+        }
+    }
+    p->prof->enabled = enable != 0;
+    p->prof->n = 0;
+    p->prof->dropped = 0;
+    return VA_OK;
+}
+
+int va_pipeline_stage_times(va_pipeline_t *p, int capacity, char *names, double *total_ms,
+                            int32_t *launches, int *nstages_out)
+{
+    VA_REQUIRE(p && names && total_ms && launches && nstages_out && capacity > 0,
+               "va_pipeline_stage_times: bad argument");
+    *nstages_out = 0;
+    if (!p->prof || p->prof->n == 0)
+        return VA_OK;
+    StageProfiler &pr = *p->prof;
+    VA_HIP(hipEventSynchronize(pr.ev[pr.n - 1]));
+    int ns = 0;
+    for (int i = 1; i < pr.n; i++) {
+        if (!pr.name[i])
+            continue;  // start-of-run marker
+        float ms = 0.f;
+        VA_HIP(hipEventElapsedTime(&ms, pr.ev[i - 1], pr.ev[i]));
+        int k = 0;
+        for (; k < ns; k++)
+            if (strncmp(names + (size_t)k * 32, pr.name[i], 31) == 0)
+                break;
+        if (k == ns) {
+            if (ns == capacity)
+                continue;
+            strncpy(names + (size_t)k * 32, pr.name[i], 31);
+            names[(size_t)k * 32 + 31] = 0;
+            total_ms[k] = 0;
+            launches[k] = 0;
+            ns++;
+        }
+        total_ms[k] += ms;
+        launches[k] += 1;
+    }
+    *nstages_out = ns;
     return VA_OK;
 }
 

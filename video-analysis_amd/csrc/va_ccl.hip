@@ -543,8 +543,13 @@ size_t ccl_workspace_bytes(int n, int h, int w)
 // workspace here = row_cnt + row_off only (the caller owns the bit mask)
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st)
+               hipStream_t st, StageProfiler *prof)
 {
+#define VA_MARK(nm)      \
+    do {                 \
+        if (prof)        \
+            prof->mark(nm, st); \
+    } while (0)
     VA_REQUIRE(connectivity == 4 || connectivity == 8, "label: connectivity must be 4 or 8 (got %d)",
                connectivity);
     VA_REQUIRE(bits && labels && workspace, "label: NULL argument");
@@ -561,23 +566,29 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
 
     ccl_init_kernel<<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
     VA_LAUNCH_CHECK("ccl_init_kernel");
+    VA_MARK("ccl_init");
     if (connectivity == 8)
         ccl_link_kernel<true><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
     else
         ccl_link_kernel<false><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
     VA_LAUNCH_CHECK("ccl_link_kernel");
+    VA_MARK("ccl_link");
     ccl_flatten_kernel<<<grid, kBlock, 0, st>>>(bits, labels, row_cnt, h, w, w32, total_rows);
     VA_LAUNCH_CHECK("ccl_flatten_kernel");
+    VA_MARK("ccl_flatten");
     ccl_rowscan_kernel<<<n, kBlock, 0, st>>>(row_cnt, row_off, counts, h);
     VA_LAUNCH_CHECK("ccl_rowscan_kernel");
+    VA_MARK("ccl_rowscan");
     ccl_rank_kernel<<<grid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, total_rows);
     VA_LAUNCH_CHECK("ccl_rank_kernel");
+    VA_MARK("ccl_rank");
     const int vec = (w % 4 == 0) && aligned(labels, 16);
     if (stats && max_labels > 0) {
         size_t entries = (size_t)n * max_labels;
         stats_init_kernel<<<cdiv((long long)entries * VA_STATS_STRIDE, kBlock), kBlock, 0, st>>>(
             stats, entries, h, w);
         VA_LAUNCH_CHECK("stats_init_kernel");
+        VA_MARK("stats_init");
         ccl_paint_kernel<true><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows, stats,
                                                        max_labels, vec);
     } else {
@@ -585,6 +596,8 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
                                                         nullptr, 0, vec);
     }
     VA_LAUNCH_CHECK("ccl_paint_kernel");
+    VA_MARK("ccl_paint");
+#undef VA_MARK
     return VA_OK;
 }
 

@@ -44,6 +44,34 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+// Optional per-stage timing with HIP events on the pipeline's own stream (bench.py's roofline
+// numbers come from here).  Events are only recorded, never waited for, inside a run.
+struct StageProfiler {
+    static constexpr int kMaxMarks = 4096;
+    bool enabled = false;
+    int n = 0, dropped = 0;
+    hipEvent_t ev[kMaxMarks];
+    const char *name[kMaxMarks];  // nullptr = start of a run
+    bool created[kMaxMarks] = {};
+    void mark(const char *nm, hipStream_t st)
+    {
+        if (!enabled)
+            return;
+        if (n >= kMaxMarks) {
+            dropped++;
+            return;
+        }
+        if (!created[n]) {
+            if (hipEventCreate(&ev[n]) != hipSuccess)
+                return;
+            created[n] = true;
+        }
+        if (hipEventRecord(ev[n], st) != hipSuccess)
+            return;
+        name[n++] = nm;
+    }
+};
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline int words_per_row(int w) { return (w + 31) / 32; }
 
@@ -111,7 +139,7 @@ int launch_morph_bits(const uint32_t *src, uint32_t *dst, int n, int h, int w, i
 size_t ccl_workspace_bytes(int n, int h, int w);
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st);
+               hipStream_t st, StageProfiler *prof = nullptr);
 int launch_stats_from_labels(const int32_t *labels, int n, int h, int w, int max_labels,
                              int64_t *stats, hipStream_t st);
 int launch_largest_region(const int32_t *labels, const int32_t *counts, const int64_t *stats,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "va_bg_set_state": (_i, [_vp, _vp, _sz, _i64]),
     "va_bg_state_bytes": (_sz, [_vp]),
     "va_pipeline_describe": (C.c_char_p, [_vp]),
+    "va_pipeline_profile": (_i, [_vp, _i]),
+    "va_pipeline_stage_times": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "va_gaussian_u8_generic": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "va_morph_bits_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "va_comm_unique_id": (_i, [_vp]),

@@ -126,6 +126,25 @@ class FrameEngine(object):
             out["stats"] = ptr["stats"].download((n, self.max_labels, _hip.STATS_STRIDE), np.int64)
         return out
 
+    # ------------------------------------------------------------------ per-stage timing
+    def profile(self, enable=True):
+        """start (and reset) / stop recording one HIP event per stage on the run's stream"""
+        check(self._lib.va_pipeline_profile(self._handle, 1 if enable else 0))
+
+    def stage_times(self):
+        """{stage: (total_ms, launches)} accumulated since profile(True)"""
+        cap = 32
+        names = C.create_string_buffer(cap * 32)
+        ms = (C.c_double * cap)()
+        launches = (C.c_int32 * cap)()
+        ns = C.c_int()
+        check(self._lib.va_pipeline_stage_times(self._handle, cap, names, ms, launches, C.byref(ns)))
+        out = {}
+        for k in range(ns.value):
+            nm = names.raw[k * 32:(k + 1) * 32].split(b"\0", 1)[0].decode()
+            out[nm] = (ms[k], launches[k])
+        return out
+
     # ------------------------------------------------------------------ background state
     def get_background(self):
         """(state array, n_seen) -- float64 for 'mean'/'static', float32 for 'ema'"""
