@@ -1,11 +1,297 @@
-// va_gauss_fused.hip -- placeholder until the LDS-staged kernel lands
+// va_gauss_fused.hip -- fused single-channel 8-bit Gaussian blur (+ threshold + bit packing)
+//
+// replaces cv2.GaussianBlur(frame.astype(np.uint8), (0, 0), sigma)
+//          FilterBlur._process_frame, video/filters.py:388-392
+// and, in the pipeline, the BUILD-DEFINED FilterThreshold that follows it.
+//
+// One workgroup owns a vertical strip of TW columns of one frame and MARCHES DOWN it, eight
+// rows per step, so every input byte is read from HBM once (plus a 16-column halo) and nothing
+// but the final output is written:
+//
+//   global --(16 B/lane, prefetched one step ahead)--> s_in  : 8 staged input rows (u8)
+//   row pass : v_dot4_u32_u8 over 36-byte windows of s_in with byte-shifted copies of the q8.8
+//              taps (all taps <= 255, so four taps x four pixels are one instruction)
+//              -> u16 results, two vertically adjacent rows packed per dword -> s_t ring
+//   col pass : every thread owns one column, keeps RP+4 packed row pairs in registers and
+//              produces 8 output rows with v_dot2_u32_u16 (two rows x two taps per instruction)
+//   output   : u8 bytes, and/or (blur > thresh) as a bit mask via wave ballots (8 B per wave-row)
+//
+// Arithmetic is exactly the oracle's: row sum u16 (<= 255*256), column sum u32,
+// (acc + 2^15) >> 16.  Borders: BORDER_REFLECT_101 in both directions ("virtual" rows above and
+// below the frame are real rows fetched through the reflection).
+// One barrier per step; the s_t ring has 4 pair-rows of slack so that the next step's row pass
+// never overwrites what a slow wave still reads in this step's column pass.
 #include "va_common.h"
+
 namespace va {
-bool gauss_fused_supported(int, int, const TapsQ8 &) { return false; }
-int launch_gauss_fused_u8(const uint8_t *, uint8_t *, uint32_t *, int, int, int, int,
-                          const TapsQ8 &, hipStream_t)
+
+namespace {
+
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
 {
-    set_error("fused Gaussian not built");
-    return VA_ERR_INVALID;
+    return __builtin_amdgcn_udot4(a, b, c, false);
 }
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b),
+                                  c, false);
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1)
+        return 0;
+    while (p < 0 || p >= len)
+        p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+constexpr int kHalo = 16;   // staged columns left and right of the strip (>= padded radius)
+constexpr int kRows = 8;    // rows per step
+
+struct FusedWeights {
+    uint32_t wrow[4][9];  // byte weights for output o = 0..3 over the thread's 36-byte window
+    uint32_t we[17];      // (tap[2j], tap[2j+1]) pairs for even output rows
+    uint32_t wo[17];      // (tap[2j-1], tap[2j]) pairs for odd output rows
+};
+
+template <int TW, int RP>
+__global__ void __launch_bounds__(TW)
+gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                   uint32_t *__restrict__ bits, int thresh, int h, int w, int w32, int nstrips,
+                   FusedWeights wt, int aligned16)
+{
+    constexpr int IW = TW + 2 * kHalo;       // staged bytes per input row
+    constexpr int IWD = IW / 4;
+    constexpr int NP = kRows / 2 + RP;       // packed row pairs the column pass reads
+    constexpr int LAG = (2 * RP + 7) / 8;    // steps between producing and consuming rows
+    constexpr int RING = NP + 4;
+    constexpr int VPR = IW / 16;             // 16-byte vectors per staged row
+    constexpr int NV = VPR * kRows;
+    constexpr int UPR = TW / 4;              // row-pass units (4 pixels x 2 rows) per pair-row
+    static_assert(NV <= TW, "one prefetch vector per thread");
+    static_assert(RP <= 16 && (TW % 64) == 0, "unsupported geometry");
+
+    __shared__ __attribute__((aligned(16))) uint32_t s_in[2][kRows][IWD];
+    __shared__ __attribute__((aligned(16))) uint32_t s_t[RING][TW];
+
+    const int tid = threadIdx.x;
+    const int strip = blockIdx.x % nstrips, f = blockIdx.x / nstrips;
+    const int X0 = strip * TW;
+    const uint8_t *img = src + (size_t)f * h * w;
+    const bool interior = aligned16 && X0 >= kHalo && X0 + TW + kHalo <= w;
+    const int vrow = tid / VPR, vcol = tid % VPR;
+
+    auto load_vec = [&](int s) -> uint4 {
+        const int yy = reflect101(kRows * s + vrow - RP, h);
+        return *reinterpret_cast<const uint4 *>(img + (size_t)yy * w + (X0 - kHalo) + vcol * 16);
+    };
+    auto stage_bytes = [&](int s, int buf) {  // border strips / unaligned widths
+        for (int i = tid; i < kRows * IW; i += TW) {
+            const int row = i / IW, c = i % IW;
+            const int yy = reflect101(kRows * s + row - RP, h);
+            const int xx = reflect101(X0 - kHalo + c, w);
+            reinterpret_cast<uint8_t *>(&s_in[buf][row][0])[c] = img[(size_t)yy * w + xx];
+        }
+    };
+
+    if (interior) {
+        if (tid < NV)
+            *reinterpret_cast<uint4 *>(&s_in[0][vrow][vcol * 4]) = load_vec(0);
+    } else {
+        stage_bytes(0, 0);
+    }
+    __syncthreads();
+
+    const int nsteps = (h + kRows - 1) / kRows + LAG;
+    const int pr = tid / UPR, xq = tid % UPR;   // this thread's row-pass unit
+    const int x = X0 + tid;                     // this thread's column in the column pass
+    const int wave = tid >> 6, lane = tid & 63;
+
+    // column-pass tap pairs live in VGPRs: together with the 36 row-pass dwords they do not fit
+    // the SGPR file, and SGPR spills would cost one v_readlane per v_dot2
+    uint32_t we[RP + 1], wo[RP + 1];
+#pragma unroll
+    for (int j = 0; j <= RP; j++) {
+        we[j] = wt.we[j];
+        wo[j] = wt.wo[j];
+        asm volatile("" : "+v"(we[j]), "+v"(wo[j]));
+    }
+
+    for (int s = 0; s < nsteps; s++) {
+        const int buf = s & 1;
+        const bool more = s + 1 < nsteps;
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        const bool have_pre = interior && more && tid < NV;
+        if (have_pre)
+            pre = load_vec(s + 1);
+
+        // ---- row pass: virtual rows 8s+2pr and 8s+2pr+1, output columns 4xq..4xq+3
+        {
+            const uint32_t *r0 = &s_in[buf][2 * pr][xq];
+            const uint32_t *r1 = &s_in[buf][2 * pr + 1][xq];
+            uint32_t d0[9], d1[9];
+#pragma unroll
+            for (int d = 0; d < 9; d++) {
+                d0[d] = r0[d];
+                d1[d] = r1[d];
+            }
+            uint32_t o4[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+                for (int d = 0; d < 9; d++) {
+                    a0 = udot4(d0[d], wt.wrow[o][d], a0);
+                    a1 = udot4(d1[d], wt.wrow[o][d], a1);
+                }
+                o4[o] = a0 | (a1 << 16);   // both <= 255*256
+            }
+            const int slot = (4 * s + pr) % RING;
+            *reinterpret_cast<uint4 *>(&s_t[slot][4 * xq]) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        }
+
+        // ---- stage the next step's input rows into the other buffer
+        if (more) {
+            if (interior) {
+                if (have_pre)
+                    *reinterpret_cast<uint4 *>(&s_in[buf ^ 1][vrow][vcol * 4]) = pre;
+            } else {
+                stage_bytes(s + 1, buf ^ 1);
+            }
+        }
+        __syncthreads();
+
+        // ---- column pass: output rows 8g..8g+7 of column x
+        const int g = s - LAG;
+        if (g >= 0 && kRows * g < h) {
+            uint32_t pd[NP];
+            int slot = (4 * g) % RING;
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                pd[j] = s_t[slot][tid];
+                slot = slot + 1 == RING ? 0 : slot + 1;
+            }
+#pragma unroll
+            for (int i = 0; i < kRows; i++) {
+                const int y = kRows * g + i;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j <= RP; j++)
+                    acc = udot2(pd[i / 2 + j], (i & 1) ? wo[j] : we[j], acc);
+                const uint32_t v = (acc + 32768u) >> 16;
+                const bool inside = y < h && x < w;
+                if (dst && inside)
+                    dst[((size_t)f * h + y) * w + x] = (uint8_t)v;
+                if (bits) {
+                    const unsigned long long b = __ballot(inside && (int)v > thresh);
+                    const int wbase = (X0 >> 5) + wave * 2;
+                    if (y < h && lane < 2 && wbase + lane < w32)
+                        bits[((size_t)f * h + y) * w32 + wbase + lane] =
+                            lane ? (uint32_t)(b >> 32) : (uint32_t)b;
+                }
+            }
+        }
+    }
+}
+
+bool build_weights(const TapsQ8 &taps, int RP, FusedWeights *wt)
+{
+    const int r = taps.ksize / 2;
+    if (r > RP || RP > 16)
+        return false;
+    uint32_t P[2 * 16 + 2] = {};   // zero-padded taps, centred at RP
+    for (int i = 0; i < taps.ksize; i++) {
+        if (taps.t[i] > 255)
+            return false;
+        P[i + RP - r] = taps.t[i];
+    }
+    memset(wt, 0, sizeof(*wt));
+    for (int o = 0; o < 4; o++)
+        for (int j = 0; j < 36; j++) {
+            const int i = j - (kHalo - RP + o);
+            if (i >= 0 && i <= 2 * RP)
+                wt->wrow[o][j / 4] |= P[i] << (8 * (j % 4));
+        }
+    for (int j = 0; j <= RP; j++) {
+        const uint32_t lo_e = P[2 * j], hi_e = (2 * j + 1 <= 2 * RP) ? P[2 * j + 1] : 0;
+        const uint32_t lo_o = j > 0 ? P[2 * j - 1] : 0, hi_o = P[2 * j];
+        wt->we[j] = lo_e | (hi_e << 16);
+        wt->wo[j] = lo_o | (hi_o << 16);
+    }
+    return true;
+}
+
+int padded_radius(int r) { return r <= 4 ? 4 : (r <= 8 ? 8 : 16); }
+
+// strip width that wastes the fewest columns (ties: the wider strip, fewer halo re-reads)
+int pick_tw(int w)
+{
+    const int cand[3] = {256, 192, 128};
+    int best = 256, best_cols = 1 << 30;
+    for (int tw : cand) {
+        int cols = cdiv(w, tw) * tw;
+        if (cols < best_cols) {
+            best_cols = cols;
+            best = tw;
+        }
+    }
+    return best;
+}
+
+template <int TW>
+int launch_tw(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n, int h, int w,
+              int RP, const FusedWeights &wt, int aligned16, hipStream_t st)
+{
+    const int nstrips = cdiv(w, TW);
+    const int w32 = words_per_row(w);
+    dim3 grid((unsigned)(nstrips * n));
+    if (RP == 4)
+        gauss_fused_kernel<TW, 4><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt, aligned16);
+    else if (RP == 8)
+        gauss_fused_kernel<TW, 8><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt, aligned16);
+    else
+        gauss_fused_kernel<TW, 16><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt, aligned16);
+    VA_LAUNCH_CHECK("gauss_fused_kernel");
+    return VA_OK;
+}
+
+}  // namespace
+
+bool gauss_fused_supported(int w, int h, const TapsQ8 &taps)
+{
+    (void)w;
+    (void)h;
+    if (taps.ksize < 3 || taps.ksize / 2 > 16)
+        return false;
+    for (int i = 0; i < taps.ksize; i++)
+        if (taps.t[i] > 255)
+            return false;
+    return true;
+}
+
+int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,
+                          int h, int w, const TapsQ8 &taps, hipStream_t st)
+{
+    VA_REQUIRE(src && (dst || bits), "fused gaussian: no output requested");
+    VA_REQUIRE(gauss_fused_supported(w, h, taps), "fused gaussian: unsupported kernel size %d",
+               taps.ksize);
+    if (n == 0)
+        return VA_OK;
+    const int RP = padded_radius(taps.ksize / 2);
+    FusedWeights wt;
+    VA_REQUIRE(build_weights(taps, RP, &wt), "fused gaussian: cannot build the weight tables");
+    const int aligned16 = (w % 16 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+    switch (pick_tw(w)) {
+    case 128:
+        return launch_tw<128>(src, dst, bits, thresh, n, h, w, RP, wt, aligned16, st);
+    case 192:
+        return launch_tw<192>(src, dst, bits, thresh, n, h, w, RP, wt, aligned16, st);
+    default:
+        return launch_tw<256>(src, dst, bits, thresh, n, h, w, RP, wt, aligned16, st);
+    }
+}
+
 }  // namespace va
