@@ -207,7 +207,7 @@ int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
     int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
     if (rc)
         return rc;
-    if (c == 1 && gauss_fused_supported(w, h, t))
+    if (c == 1 && gauss_fused_supported(w, h, t) && reinterpret_cast<uintptr_t>(src) % 16 == 0)
         return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
     void *scratch;
     rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);

@@ -39,13 +39,15 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
                                   c, false);
 }
 
+// BORDER_REFLECT_101 for indices that overshoot the frame by less than its size (frames are
+// at least 32 x 32 here and the halo is 16, see gauss_fused_supported), branch-free.  Indices
+// further out belong to columns/rows whose results are never stored: they are only clamped
+// so that the load stays inside the frame.
 __device__ __forceinline__ int reflect101(int p, int len)
 {
-    if (len == 1)
-        return 0;
-    while (p < 0 || p >= len)
-        p = p < 0 ? -p : 2 * (len - 1) - p;
-    return p;
+    p = p < 0 ? -p : p;
+    p = p >= len ? 2 * (len - 1) - p : p;
+    return min(max(p, 0), len - 1);
 }
 
 constexpr int kHalo = 16;   // staged columns left and right of the strip (>= padded radius)
@@ -61,7 +63,7 @@ template <int TW, int RP>
 __global__ void __launch_bounds__(TW)
 gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                    uint32_t *__restrict__ bits, int thresh, int h, int w, int w32, int nstrips,
-                   FusedWeights wt, int aligned16)
+                   FusedWeights wt)
 {
     constexpr int IW = TW + 2 * kHalo;       // staged bytes per input row
     constexpr int IWD = IW / 4;
@@ -81,28 +83,43 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     const int strip = blockIdx.x % nstrips, f = blockIdx.x / nstrips;
     const int X0 = strip * TW;
     const uint8_t *img = src + (size_t)f * h * w;
-    const bool interior = aligned16 && X0 >= kHalo && X0 + TW + kHalo <= w;
     const int vrow = tid / VPR, vcol = tid % VPR;
+    // This thread stages 16 columns [gx0, gx0+16) of one row per step.  Frame rows are 16-byte
+    // aligned and w % 16 == 0, so a vector lies entirely inside the frame or entirely outside.
+    // Outside vectors exist only next to the left/right frame border; they are the mirror
+    // image (BORDER_REFLECT_101) of in-frame columns and are assembled in registers from two
+    // aligned loads:   left : t[i] = col(16 - i)      right: t[i] = col(w - 2 - i)
+    const int gx0 = X0 - kHalo + vcol * 16;
+    const int kind = gx0 >= 0 && gx0 + 16 <= w ? 0 : (gx0 == -16 ? 1 : (gx0 == w ? 2 : 3));
 
-    auto load_vec = [&](int s) -> uint4 {
+    auto ld16 = [&](const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); };
+    auto fetch = [&](int s) -> uint4 {
         const int yy = reflect101(kRows * s + vrow - RP, h);
-        return *reinterpret_cast<const uint4 *>(img + (size_t)yy * w + (X0 - kHalo) + vcol * 16);
-    };
-    auto stage_bytes = [&](int s, int buf) {  // border strips / unaligned widths
-        for (int i = tid; i < kRows * IW; i += TW) {
-            const int row = i / IW, c = i % IW;
-            const int yy = reflect101(kRows * s + row - RP, h);
-            const int xx = reflect101(X0 - kHalo + c, w);
-            reinterpret_cast<uint8_t *>(&s_in[buf][row][0])[c] = img[(size_t)yy * w + xx];
+        const uint8_t *rowp = img + (size_t)yy * w;
+        if (kind == 0)
+            return ld16(rowp + gx0);
+        if (kind == 1) {
+            const uint4 A = ld16(rowp), B = ld16(rowp + 16);
+            const uint32_t r0 = __builtin_bswap32(A.w), r1 = __builtin_bswap32(A.z),
+                           r2 = __builtin_bswap32(A.y), r3 = __builtin_bswap32(A.x);
+            return make_uint4((r0 << 8) | (B.x & 0xFFu), __builtin_amdgcn_alignbyte(r1, r0, 3),
+                              __builtin_amdgcn_alignbyte(r2, r1, 3),
+                              __builtin_amdgcn_alignbyte(r3, r2, 3));
         }
+        if (kind == 2) {
+            const uint4 C = ld16(rowp + w - 32), D = ld16(rowp + w - 16);
+            const uint32_t r0 = __builtin_bswap32(D.w), r1 = __builtin_bswap32(D.z),
+                           r2 = __builtin_bswap32(D.y), r3 = __builtin_bswap32(D.x);
+            return make_uint4(__builtin_amdgcn_alignbyte(r1, r0, 1),
+                              __builtin_amdgcn_alignbyte(r2, r1, 1),
+                              __builtin_amdgcn_alignbyte(r3, r2, 1),
+                              (r3 >> 8) | (C.w & 0xFF000000u));
+        }
+        return make_uint4(0, 0, 0, 0);   // columns whose results are never stored
     };
 
-    if (interior) {
-        if (tid < NV)
-            *reinterpret_cast<uint4 *>(&s_in[0][vrow][vcol * 4]) = load_vec(0);
-    } else {
-        stage_bytes(0, 0);
-    }
+    if (tid < NV)
+        *reinterpret_cast<uint4 *>(&s_in[0][vrow][vcol * 4]) = fetch(0);
     __syncthreads();
 
     const int nsteps = (h + kRows - 1) / kRows + LAG;
@@ -124,9 +141,9 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
         const int buf = s & 1;
         const bool more = s + 1 < nsteps;
         uint4 pre = make_uint4(0, 0, 0, 0);
-        const bool have_pre = interior && more && tid < NV;
+        const bool have_pre = more && tid < NV;
         if (have_pre)
-            pre = load_vec(s + 1);
+            pre = fetch(s + 1);
 
         // ---- row pass: virtual rows 8s+2pr and 8s+2pr+1, output columns 4xq..4xq+3
         {
@@ -138,30 +155,30 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                 d0[d] = r0[d];
                 d1[d] = r1[d];
             }
+            // eight independent accumulators, taps outermost: back-to-back v_dot4 on one
+            // accumulator would need a wait state each
+            uint32_t a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int d = 0; d < 9; d++) {
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    a0[o] = udot4(d0[d], wt.wrow[o][d], a0[o]);
+                    a1[o] = udot4(d1[d], wt.wrow[o][d], a1[o]);
+                }
+                asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]),
+                                  "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));
+            }
             uint32_t o4[4];
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                uint32_t a0 = 0, a1 = 0;
-#pragma unroll
-                for (int d = 0; d < 9; d++) {
-                    a0 = udot4(d0[d], wt.wrow[o][d], a0);
-                    a1 = udot4(d1[d], wt.wrow[o][d], a1);
-                }
-                o4[o] = a0 | (a1 << 16);   // both <= 255*256
-            }
+            for (int o = 0; o < 4; o++)
+                o4[o] = a0[o] | (a1[o] << 16);   // both <= 255*256
             const int slot = (4 * s + pr) % RING;
             *reinterpret_cast<uint4 *>(&s_t[slot][4 * xq]) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
         }
 
         // ---- stage the next step's input rows into the other buffer
-        if (more) {
-            if (interior) {
-                if (have_pre)
-                    *reinterpret_cast<uint4 *>(&s_in[buf ^ 1][vrow][vcol * 4]) = pre;
-            } else {
-                stage_bytes(s + 1, buf ^ 1);
-            }
-        }
+        if (have_pre)
+            *reinterpret_cast<uint4 *>(&s_in[buf ^ 1][vrow][vcol * 4]) = pre;
         __syncthreads();
 
         // ---- column pass: output rows 8g..8g+7 of column x
@@ -174,24 +191,38 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                 pd[j] = s_t[slot][tid];
                 slot = slot + 1 == RING ? 0 : slot + 1;
             }
+            uint32_t acc[kRows];
+#pragma unroll
+            for (int i = 0; i < kRows; i++)
+                acc[i] = 0;
+#pragma unroll
+            for (int j = 0; j <= RP; j++) {      // taps outermost: 8 independent dot2 chains
+#pragma unroll
+                for (int i = 0; i < kRows; i++)
+                    acc[i] = udot2(pd[i / 2 + j], (i & 1) ? wo[j] : we[j], acc[i]);
+                // pin the interleaved order (the scheduler would otherwise re-serialise the chains)
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]),
+                                  "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
+            }
+            const int y0 = kRows * g;
+            const bool xin = x < w;
+            uint32_t myword = 0;                 // lane l < 16 stores row l>>1, half l&1
 #pragma unroll
             for (int i = 0; i < kRows; i++) {
-                const int y = kRows * g + i;
-                uint32_t acc = 0;
-#pragma unroll
-                for (int j = 0; j <= RP; j++)
-                    acc = udot2(pd[i / 2 + j], (i & 1) ? wo[j] : we[j], acc);
-                const uint32_t v = (acc + 32768u) >> 16;
-                const bool inside = y < h && x < w;
-                if (dst && inside)
-                    dst[((size_t)f * h + y) * w + x] = (uint8_t)v;
+                const uint32_t v = (acc[i] + 32768u) >> 16;
+                if (dst && xin && y0 + i < h)
+                    dst[((size_t)f * h + y0 + i) * w + x] = (uint8_t)v;
                 if (bits) {
-                    const unsigned long long b = __ballot(inside && (int)v > thresh);
-                    const int wbase = (X0 >> 5) + wave * 2;
-                    if (y < h && lane < 2 && wbase + lane < w32)
-                        bits[((size_t)f * h + y) * w32 + wbase + lane] =
-                            lane ? (uint32_t)(b >> 32) : (uint32_t)b;
+                    const unsigned long long b = __ballot(xin && (int)v > thresh);
+                    const uint32_t half = (lane & 1) ? (uint32_t)(b >> 32) : (uint32_t)b;
+                    myword = (lane >> 1) == i ? half : myword;
                 }
+            }
+            if (bits) {
+                const int wi = (X0 >> 5) + wave * 2 + (lane & 1);
+                const int yy = y0 + (lane >> 1);
+                if (lane < 2 * kRows && yy < h && wi < w32)
+                    bits[((size_t)f * h + yy) * w32 + wi] = myword;
             }
         }
     }
@@ -243,17 +274,17 @@ int pick_tw(int w)
 
 template <int TW>
 int launch_tw(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n, int h, int w,
-              int RP, const FusedWeights &wt, int aligned16, hipStream_t st)
+              int RP, const FusedWeights &wt, hipStream_t st)
 {
     const int nstrips = cdiv(w, TW);
     const int w32 = words_per_row(w);
     dim3 grid((unsigned)(nstrips * n));
     if (RP == 4)
-        gauss_fused_kernel<TW, 4><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt, aligned16);
+        gauss_fused_kernel<TW, 4><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt);
     else if (RP == 8)
-        gauss_fused_kernel<TW, 8><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt, aligned16);
+        gauss_fused_kernel<TW, 8><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt);
     else
-        gauss_fused_kernel<TW, 16><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt, aligned16);
+        gauss_fused_kernel<TW, 16><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt);
     VA_LAUNCH_CHECK("gauss_fused_kernel");
     return VA_OK;
 }
@@ -262,8 +293,8 @@ int launch_tw(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int 
 
 bool gauss_fused_supported(int w, int h, const TapsQ8 &taps)
 {
-    (void)w;
-    (void)h;
+    if (w < 32 || h < 32 || (w % 16) != 0)   // single reflection; 16-byte aligned rows
+        return false;
     if (taps.ksize < 3 || taps.ksize / 2 > 16)
         return false;
     for (int i = 0; i < taps.ksize; i++)
@@ -283,14 +314,15 @@ int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int 
     const int RP = padded_radius(taps.ksize / 2);
     FusedWeights wt;
     VA_REQUIRE(build_weights(taps, RP, &wt), "fused gaussian: cannot build the weight tables");
-    const int aligned16 = (w % 16 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+    VA_REQUIRE(reinterpret_cast<uintptr_t>(src) % 16 == 0,
+               "fused gaussian: the frame buffer must be 16-byte aligned");
     switch (pick_tw(w)) {
     case 128:
-        return launch_tw<128>(src, dst, bits, thresh, n, h, w, RP, wt, aligned16, st);
+        return launch_tw<128>(src, dst, bits, thresh, n, h, w, RP, wt, st);
     case 192:
-        return launch_tw<192>(src, dst, bits, thresh, n, h, w, RP, wt, aligned16, st);
+        return launch_tw<192>(src, dst, bits, thresh, n, h, w, RP, wt, st);
     default:
-        return launch_tw<256>(src, dst, bits, thresh, n, h, w, RP, wt, aligned16, st);
+        return launch_tw<256>(src, dst, bits, thresh, n, h, w, RP, wt, st);
     }
 }
 
