@@ -46,6 +46,7 @@ STAGE_BYTES_PER_PX = {
     "gauss_fused": 1 + 1 / 8,    # u8 in, thresholded bit mask out
     "gauss_generic": 1 + 1,      # u8 in, u8 out (the u16 scratch round trip is NOT compulsory)
     "threshold_pack": 1 + 1 / 8,
+    "morph_fused": 2 / 8,        # bit mask in, bit mask out (+ forest seeds, sparse)
     "morph_dilate": 2 / 8,
     "morph_erode": 2 / 8,
     "mask_unpack": 1 / 8 + 1,

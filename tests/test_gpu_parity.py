@@ -124,6 +124,23 @@ def test_running_mean_split_batches_and_odd_sizes(ops, oracle):
         assert np.array_equal(m3.process(fr[6:]), rd[6:])
 
 
+def test_running_mean_division_free_path_is_bit_exact(ops, oracle):
+    """the kernel replaces (mean*n)/(n+1) by a reciprocal + two FMA corrections and frame/(n+1) by
+    a table: both must equal IEEE division bit for bit, for any state and frame count"""
+    rng = np.random.default_rng(23)
+    shape = (40, 16, 24)                      # px % 8 == 0 -> the division-free kernel
+    fr = rng.integers(0, 256, shape, dtype=np.uint8)
+    for n_seen in (0, 1, 2, 3, 7, 1000, 123457, 2 ** 31 - 100, 2 ** 40 + 12345):
+        state = rng.random(shape[1:]) * 255   # arbitrary float64 significands
+        state[0, :6] = [0.0, 255.0, 1e-300, 254.99999999999997, 1.0 / 3.0, 5e-324]
+        rd, rm = oracle.bg_mean_u8(fr, mean=state, n_seen=n_seen)
+        m = ops.BackgroundModel(shape[1:], "mean")
+        m.set_state(state, n_seen)
+        d = m.process(fr)
+        assert np.array_equal(d, rd), n_seen
+        assert np.array_equal(m.state, rm), n_seen
+
+
 def test_ema_static_welford(ops, oracle, golden):
     rng = np.random.default_rng(22)
     fr = rng.integers(0, 256, (30, 12, 20), dtype=np.uint8)

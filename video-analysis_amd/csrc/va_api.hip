@@ -62,6 +62,7 @@ struct va_pipeline {
     void *bg_state;
     size_t bg_bytes;
     int64_t n_seen;
+    double *bg_tables; // per-frame division tables of the running mean
     void *diff;        // background-subtracted frames (cfg.dtype)
     void *blur;        // blurred frames when the caller does not ask for them (generic path)
     void *gscratch;    // generic Gaussian scratch (u16 / f32)
@@ -254,7 +255,16 @@ int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, do
 int va_bg_update(int mode, int dtype, const void *frames, void *diff_out, void *state,
                  int64_t n_seen, double rate, int n, size_t px, void *stream)
 {
-    return launch_bg(mode, dtype, frames, diff_out, state, n_seen, rate, n, px, as_stream(stream));
+    double *tables = nullptr;
+    if (mode == VA_BG_MEAN && dtype == VA_U8 && n > 0) {
+        void *scratch;
+        int rc = get_scratch(bg_tables_bytes(n), &scratch);
+        if (rc)
+            return rc;
+        tables = (double *)scratch;
+    }
+    return launch_bg(mode, dtype, frames, diff_out, state, n_seen, rate, n, px, as_stream(stream),
+                     tables);
 }
 int va_welford_u8(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
                   size_t px, void *stream)
@@ -369,7 +379,7 @@ int va_largest_region(const int32_t *labels, const int32_t *counts, const int64_
 // ------------------------------------------------------------------------------ pipeline
 static int pipeline_free(va_pipeline *p)
 {
-    void *ptrs[] = {p->bg_state, p->diff, p->blur, p->gscratch, p->bits[0], p->bits[1],
+    void *ptrs[] = {p->bg_state, p->bg_tables, p->diff, p->blur, p->gscratch, p->bits[0], p->bits[1],
                     p->ccl_ws,   p->labels_scratch, p->counts_scratch};
     for (void *q : ptrs)
         if (q)
@@ -477,6 +487,8 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
             return VA_ERR_HIP;
         }
         PIPE_MALLOC(p->diff, nb * p->px * esz);
+        if (cfg->bg_mode == VA_BG_MEAN)
+            PIPE_MALLOC(p->bg_tables, bg_tables_bytes(cfg->max_batch));
     }
     if (cfg->sigma > 0 && !p->fused) {
         PIPE_MALLOC(p->gscratch, nb * p->px * (cfg->dtype == VA_U8 ? 2 : 4));
@@ -580,7 +592,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     // 1. background subtraction (temporal, in frame order)
     if (c.bg_mode != VA_BG_NONE) {
         rc = launch_bg(c.bg_mode, c.dtype, cur, p->diff, p->bg_state, p->n_seen, (double)c.bg_rate,
-                       n, p->px, st);
+                       n, p->px, st, p->bg_tables);
         if (rc)
             return rc;
         p->n_seen += n;
@@ -630,24 +642,12 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             return rc;
         VA_MARK("threshold_pack");
     }
-    // 4. morphology on bits
-    for (int i = 0; i < c.morph_count; i++) {
-        rc = launch_morph_bits(p->bits[b], p->bits[b ^ 1], n, c.height, c.width, c.morph_op[i],
-                               p->se[i], st);
-        if (rc)
-            return rc;
-        b ^= 1;
-        VA_MARK(c.morph_op[i] == VA_MORPH_DILATE ? "morph_dilate" : "morph_erode");
-    }
-    if (mask_out) {
-        rc = launch_unpack_bits(p->bits[b], mask_out, n, c.height, c.width, c.maxval, st);
-        if (rc)
-            return rc;
-        VA_MARK("mask_unpack");
-    }
-    // 5. labelling (+ statistics)
-    if (c.connectivity && (labels_out || counts_out || stats_out)) {
-        int32_t *labels = labels_out;
+    // 4. morphology on bits (one fused LDS kernel when the sequence allows it); when labels are
+    //    wanted the fused kernel also plants the labelling forest
+    const bool want_ccl = c.connectivity && (labels_out || counts_out || stats_out);
+    int32_t *labels = nullptr;
+    if (want_ccl) {
+        labels = labels_out;
         if (!labels) {
             if (!p->labels_scratch) {
                 hipError_t e = hipMalloc((void **)&p->labels_scratch,
@@ -660,9 +660,37 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             }
             labels = p->labels_scratch;
         }
+    }
+    bool forest_ready = false;
+    if (c.morph_count > 0 && morph_fused_supported(c.width, p->se, c.morph_count)) {
+        rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], labels, n, c.height, c.width, c.morph_op,
+                                p->se, c.morph_count, st);
+        if (rc)
+            return rc;
+        b ^= 1;
+        forest_ready = labels != nullptr;
+        VA_MARK("morph_fused");
+    } else {
+        for (int i = 0; i < c.morph_count; i++) {
+            rc = launch_morph_bits(p->bits[b], p->bits[b ^ 1], n, c.height, c.width, c.morph_op[i],
+                                   p->se[i], st);
+            if (rc)
+                return rc;
+            b ^= 1;
+            VA_MARK(c.morph_op[i] == VA_MORPH_DILATE ? "morph_dilate" : "morph_erode");
+        }
+    }
+    if (mask_out) {
+        rc = launch_unpack_bits(p->bits[b], mask_out, n, c.height, c.width, c.maxval, st);
+        if (rc)
+            return rc;
+        VA_MARK("mask_unpack");
+    }
+    // 5. labelling (+ statistics)
+    if (want_ccl) {
         rc = launch_ccl(p->bits[b], labels, counts_out ? counts_out : p->counts_scratch, n,
                         c.height, c.width, c.connectivity, p->ccl_ws, p->ccl_ws_bytes, stats_out,
-                        c.max_labels, st, prof);
+                        c.max_labels, st, prof, forest_ready);
         if (rc)
             return rc;
     }

@@ -543,7 +543,7 @@ size_t ccl_workspace_bytes(int n, int h, int w)
 // workspace here = row_cnt + row_off only (the caller owns the bit mask)
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st, StageProfiler *prof)
+               hipStream_t st, StageProfiler *prof, bool forest_ready)
 {
 #define VA_MARK(nm)      \
     do {                 \
@@ -564,9 +564,11 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     int32_t *row_off = (int32_t *)((char *)workspace + up(total_rows * sizeof(int32_t)));
     const int grid = cdiv((long long)total_rows, kRowsPerBlock);
 
-    ccl_init_kernel<<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
-    VA_LAUNCH_CHECK("ccl_init_kernel");
-    VA_MARK("ccl_init");
+    if (!forest_ready) {
+        ccl_init_kernel<<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+        VA_LAUNCH_CHECK("ccl_init_kernel");
+        VA_MARK("ccl_init");
+    }
     if (connectivity == 8)
         ccl_link_kernel<true><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
     else

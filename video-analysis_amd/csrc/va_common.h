@@ -103,8 +103,11 @@ bool gauss_fused_supported(int w, int h, const TapsQ8 &taps);
 int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,
                           int h, int w, const TapsQ8 &taps, hipStream_t st);
 
+// tables: bg_tables_bytes(n) bytes of device scratch for the division-free running mean
+// (nullptr: plain IEEE divisions)
+size_t bg_tables_bytes(int n);
 int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, int64_t n_seen,
-              double rate, int n, size_t px, hipStream_t st);
+              double rate, int n, size_t px, hipStream_t st, double *tables = nullptr);
 int launch_welford(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
                    size_t px, hipStream_t st);
 
@@ -135,11 +138,17 @@ int launch_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int o
 int launch_morph_bits(const uint32_t *src, uint32_t *dst, int n, int h, int w, int op,
                       const RowSpans &se, hipStream_t st);
 
+// the whole op sequence in one LDS-resident kernel; labels_init != nullptr also plants the
+// labelling forest (then pass forest_ready = true to launch_ccl)
+bool morph_fused_supported(int w, const RowSpans *se, int count);
+int launch_morph_fused(const uint32_t *src, uint32_t *dst, int32_t *labels_init, int n, int h,
+                       int w, const int *ops, const RowSpans *se, int count, hipStream_t st);
+
 // connected components on bit masks; labels doubles as the union-find forest
 size_t ccl_workspace_bytes(int n, int h, int w);
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st, StageProfiler *prof = nullptr);
+               hipStream_t st, StageProfiler *prof = nullptr, bool forest_ready = false);
 int launch_stats_from_labels(const int32_t *labels, int n, int h, int w, int max_labels,
                              int64_t *stats, hipStream_t st);
 int launch_largest_region(const int32_t *labels, const int32_t *counts, const int64_t *stats,

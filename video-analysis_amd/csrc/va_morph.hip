@@ -165,6 +165,124 @@ morph_bits_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, 
     dst[t] = acc;
 }
 
+// ------------------------------------------------------------------ fused op sequence on bits
+// The pipeline's whole morphology chain (e.g. 5x5 dilate then 5x5 erode) in one kernel: a block
+// owns a band of kBandRows rows of one frame, stages the band plus the chain's total vertical
+// reach in LDS and applies the ops LDS -> LDS; only the final band is written.  Optionally the
+// last op also plants the union-find forest of the labelling stage (every run's first pixel
+// points at itself), which saves that stage a pass over the mask.
+struct MorphSeq {
+    int count;
+    int reach_total;            // sum over ops of max(anchor, ksize-1-anchor)
+    int op[VA_MAX_MORPH_OPS];   // VA_MORPH_*
+    RowSpans se[VA_MAX_MORPH_OPS];
+};
+constexpr int kBandRows = 32;
+
+__device__ __forceinline__ uint32_t morph_word_lds(const uint32_t *buf, int rbase, int y, int wi,
+                                                  int h, int w32, uint32_t last_valid,
+                                                  const RowSpans &se, bool dilate)
+{
+    const uint32_t border = dilate ? 0u : 0xFFFFFFFFu;
+    uint32_t acc = border;
+    for (int i = 0; i < se.ksize; i++) {
+        const int yy = y + i - se.anchor;
+        if (yy < 0 || yy >= h)
+            continue;
+        const int lo = se.lo[i] - se.anchor, hi = se.hi[i] - 1 - se.anchor;
+        if (lo > hi)
+            continue;
+        const uint32_t *row = buf + (size_t)(yy - rbase) * w32;
+        uint32_t c = row[wi];
+        uint32_t l = wi > 0 ? row[wi - 1] : border;
+        uint32_t r = wi + 1 < w32 ? row[wi + 1] : border;
+        if (!dilate) {
+            if (wi == w32 - 1)
+                c |= ~last_valid;
+            if (wi + 1 == w32 - 1)
+                r |= ~last_valid;
+        }
+        uint32_t racc = border;
+        for (int dx = lo; dx <= hi; dx++) {
+            uint32_t sft;
+            if (dx == 0)
+                sft = c;
+            else if (dx > 0)
+                sft = (c >> dx) | (r << (32 - dx));
+            else
+                sft = (c << -dx) | (l >> (32 + dx));
+            racc = dilate ? (racc | sft) : (racc & sft);
+        }
+        acc = dilate ? (acc | racc) : (acc & racc);
+    }
+    if (wi == w32 - 1)
+        acc &= last_valid;
+    return acc;
+}
+
+__global__ void __launch_bounds__(kBlock)
+morph_fused_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                   int32_t *__restrict__ labels, int h, int w, int w32, int nbands, MorphSeq seq)
+{
+    extern __shared__ uint32_t s_rows[];   // 2 x (kBandRows + 2*reach_total) x w32
+    const int band = blockIdx.x % nbands, f = blockIdx.x / nbands;
+    const int y0 = band * kBandRows;
+    const int nrows = kBandRows + 2 * seq.reach_total;
+    const int rbase = y0 - seq.reach_total;            // frame row of LDS row 0
+    uint32_t *bufA = s_rows, *bufB = s_rows + (size_t)nrows * w32;
+    const uint32_t *fsrc = src + (size_t)f * h * w32;
+    const int tail = w & 31;
+    const uint32_t last_valid = tail ? (0xFFFFFFFFu >> (32 - tail)) : 0xFFFFFFFFu;
+
+    for (int i = threadIdx.x; i < nrows * w32; i += kBlock) {
+        const int y = rbase + i / w32;
+        bufA[i] = (y >= 0 && y < h) ? fsrc[(size_t)y * w32 + i % w32] : 0u;
+    }
+    __syncthreads();
+
+    int reach = 0;
+    for (int k = 0; k < seq.count; k++) {
+        const RowSpans &se = seq.se[k];
+        const int a = se.anchor, b = se.ksize - 1 - se.anchor;
+        reach += a > b ? a : b;
+        // rows this op must produce for the ops after it
+        const int lo = max(0, rbase + reach), hi = min(h, rbase + nrows - reach);
+        const bool dil = seq.op[k] == VA_MORPH_DILATE;
+        const int cnt = (hi - lo) * w32;
+        for (int i = threadIdx.x; i < cnt; i += kBlock) {
+            const int y = lo + i / w32, wi = i % w32;
+            bufB[(size_t)(y - rbase) * w32 + wi] =
+                morph_word_lds(bufA, rbase, y, wi, h, w32, last_valid, se, dil);
+        }
+        __syncthreads();
+        uint32_t *t = bufA;
+        bufA = bufB;
+        bufB = t;
+    }
+
+    // write the band (+ plant the labelling forest)
+    const int yend = min(h, y0 + kBandRows);
+    const int cnt = (yend - y0) * w32;
+    uint32_t *fdst = dst + (size_t)f * h * w32;
+    int32_t *L = labels ? labels + (size_t)f * h * w : nullptr;
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        const int y = y0 + i / w32, wi = i % w32;
+        const uint32_t *row = bufA + (size_t)(y - rbase) * w32;
+        const uint32_t m = row[wi];
+        fdst[(size_t)y * w32 + wi] = m;
+        if (L) {
+            const uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
+            uint32_t st = m & ~((m << 1) | prev);
+            while (st) {
+                const int bpos = __ffs(st) - 1;
+                st &= st - 1;
+                const int idx = y * w + (wi << 5) + bpos;
+                L[idx] = idx;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ morphology on u8 images
 template <bool DILATE>
 __global__ void __launch_bounds__(kBlock)
@@ -240,6 +358,43 @@ int launch_morph_bits(const uint32_t *src, uint32_t *dst, int n, int h, int w, i
     else
         morph_bits_kernel<false><<<grid, kBlock, 0, st>>>(src, dst, h, w, w32, total, se);
     VA_LAUNCH_CHECK("morph_bits_kernel");
+    return VA_OK;
+}
+
+bool morph_fused_supported(int w, const RowSpans *se, int count)
+{
+    if (count < 1 || count > VA_MAX_MORPH_OPS)
+        return false;
+    int reach = 0;
+    for (int k = 0; k < count; k++) {
+        int a = se[k].anchor, b = se[k].ksize - 1 - se[k].anchor;
+        reach += a > b ? a : b;
+    }
+    size_t lds = 2 * (size_t)(kBandRows + 2 * reach) * words_per_row(w) * sizeof(uint32_t);
+    return reach <= 16 && lds <= 64 * 1024;
+}
+
+int launch_morph_fused(const uint32_t *src, uint32_t *dst, int32_t *labels_init, int n, int h,
+                       int w, const int *ops, const RowSpans *se, int count, hipStream_t st)
+{
+    VA_REQUIRE(morph_fused_supported(w, se, count), "fused morphology: unsupported sequence");
+    if (n == 0 || h == 0 || w == 0)
+        return VA_OK;
+    MorphSeq seq;
+    memset(&seq, 0, sizeof(seq));
+    seq.count = count;
+    for (int k = 0; k < count; k++) {
+        seq.op[k] = ops[k];
+        seq.se[k] = se[k];
+        int a = se[k].anchor, b = se[k].ksize - 1 - se[k].anchor;
+        seq.reach_total += a > b ? a : b;
+    }
+    const int w32 = words_per_row(w);
+    const int nbands = cdiv(h, kBandRows);
+    const size_t lds = 2 * (size_t)(kBandRows + 2 * seq.reach_total) * w32 * sizeof(uint32_t);
+    morph_fused_kernel<<<nbands * n, kBlock, lds, st>>>(src, dst, labels_init, h, w, w32, nbands,
+                                                       seq);
+    VA_LAUNCH_CHECK("morph_fused_kernel");
     return VA_OK;
 }
 
