@@ -220,23 +220,35 @@ __device__ __forceinline__ uint32_t morph_word_lds(const uint32_t *buf, int rbas
     return acc;
 }
 
+// result[x] = src[x + dx] for |dx| <= 31, from the word and its two neighbours (funnel shift)
+__device__ __forceinline__ uint32_t shift_words(uint32_t l, uint32_t c, uint32_t r, int dx)
+{
+    if (dx == 0)
+        return c;
+    return dx > 0 ? __builtin_amdgcn_alignbit(r, c, dx) : __builtin_amdgcn_alignbit(c, l, 32 + dx);
+}
+
+// thread layout: 64 word columns x 4 rows; loops stride over rows / column chunks (no div/mod)
 __global__ void __launch_bounds__(kBlock)
 morph_fused_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
                    int32_t *__restrict__ labels, int h, int w, int w32, int nbands, MorphSeq seq)
 {
-    extern __shared__ uint32_t s_rows[];   // 2 x (kBandRows + 2*reach_total) x w32
+    extern __shared__ uint32_t s_rows[];   // 3 x (kBandRows + 2*reach_total) x w32
     const int band = blockIdx.x % nbands, f = blockIdx.x / nbands;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int y0 = band * kBandRows;
     const int nrows = kBandRows + 2 * seq.reach_total;
     const int rbase = y0 - seq.reach_total;            // frame row of LDS row 0
-    uint32_t *bufA = s_rows, *bufB = s_rows + (size_t)nrows * w32;
+    uint32_t *bufA = s_rows, *bufB = s_rows + (size_t)nrows * w32, *bufH = bufB + (size_t)nrows * w32;
     const uint32_t *fsrc = src + (size_t)f * h * w32;
     const int tail = w & 31;
     const uint32_t last_valid = tail ? (0xFFFFFFFFu >> (32 - tail)) : 0xFFFFFFFFu;
 
-    for (int i = threadIdx.x; i < nrows * w32; i += kBlock) {
-        const int y = rbase + i / w32;
-        bufA[i] = (y >= 0 && y < h) ? fsrc[(size_t)y * w32 + i % w32] : 0u;
+    for (int r = ty; r < nrows; r += 4) {
+        const int y = rbase + r;
+        const bool in = y >= 0 && y < h;
+        for (int wi = tx; wi < w32; wi += 64)
+            bufA[r * w32 + wi] = in ? fsrc[(size_t)y * w32 + wi] : 0u;
     }
     __syncthreads();
 
@@ -245,14 +257,56 @@ morph_fused_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
         const RowSpans &se = seq.se[k];
         const int a = se.anchor, b = se.ksize - 1 - se.anchor;
         reach += a > b ? a : b;
-        // rows this op must produce for the ops after it
-        const int lo = max(0, rbase + reach), hi = min(h, rbase + nrows - reach);
+        const int lo = max(0, rbase + reach), hi = min(h, rbase + nrows - reach);  // rows to produce
         const bool dil = seq.op[k] == VA_MORPH_DILATE;
-        const int cnt = (hi - lo) * w32;
-        for (int i = threadIdx.x; i < cnt; i += kBlock) {
-            const int y = lo + i / w32, wi = i % w32;
-            bufB[(size_t)(y - rbase) * w32 + wi] =
-                morph_word_lds(bufA, rbase, y, wi, h, w32, last_valid, se, dil);
+        const uint32_t border = dil ? 0u : 0xFFFFFFFFu;
+        bool rect = true;                       // same non-empty span in every element row
+        for (int i = 1; i < se.ksize; i++)
+            rect = rect && se.lo[i] == se.lo[0] && se.hi[i] == se.hi[0];
+        rect = rect && se.lo[0] < se.hi[0];
+        if (rect) {
+            // separable: horizontal pass over every input row the band needs, then vertical
+            const int dlo = se.lo[0] - a, dhi = se.hi[0] - 1 - a;
+            const int ylo = max(0, lo - a), yhi = min(h, hi + b);
+            for (int y = ylo + ty; y < yhi; y += 4) {
+                const uint32_t *row = bufA + (y - rbase) * w32;
+                for (int wi = tx; wi < w32; wi += 64) {
+                    uint32_t c = row[wi];
+                    uint32_t l = wi > 0 ? row[wi - 1] : border;
+                    uint32_t r = wi + 1 < w32 ? row[wi + 1] : border;
+                    if (!dil) {     // pixels right of the frame must not win the minimum
+                        if (wi == w32 - 1)
+                            c |= ~last_valid;
+                        if (wi + 1 == w32 - 1)
+                            r |= ~last_valid;
+                    }
+                    uint32_t racc = border;
+                    for (int dx = dlo; dx <= dhi; dx++) {
+                        const uint32_t sft = shift_words(l, c, r, dx);
+                        racc = dil ? (racc | sft) : (racc & sft);
+                    }
+                    bufH[(y - rbase) * w32 + wi] = racc;
+                }
+            }
+            __syncthreads();
+            for (int y = lo + ty; y < hi; y += 4) {
+                const int i0 = max(0, a - y), i1 = min(se.ksize, h + a - y);   // rows inside the frame
+                for (int wi = tx; wi < w32; wi += 64) {
+                    uint32_t acc = border;
+                    for (int i = i0; i < i1; i++) {
+                        const uint32_t v = bufH[(y + i - a - rbase) * w32 + wi];
+                        acc = dil ? (acc | v) : (acc & v);
+                    }
+                    if (wi == w32 - 1)
+                        acc &= last_valid;
+                    bufB[(y - rbase) * w32 + wi] = acc;
+                }
+            }
+        } else {
+            for (int y = lo + ty; y < hi; y += 4)
+                for (int wi = tx; wi < w32; wi += 64)
+                    bufB[(y - rbase) * w32 + wi] =
+                        morph_word_lds(bufA, rbase, y, wi, h, w32, last_valid, se, dil);
         }
         __syncthreads();
         uint32_t *t = bufA;
@@ -262,22 +316,22 @@ morph_fused_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
 
     // write the band (+ plant the labelling forest)
     const int yend = min(h, y0 + kBandRows);
-    const int cnt = (yend - y0) * w32;
     uint32_t *fdst = dst + (size_t)f * h * w32;
     int32_t *L = labels ? labels + (size_t)f * h * w : nullptr;
-    for (int i = threadIdx.x; i < cnt; i += kBlock) {
-        const int y = y0 + i / w32, wi = i % w32;
-        const uint32_t *row = bufA + (size_t)(y - rbase) * w32;
-        const uint32_t m = row[wi];
-        fdst[(size_t)y * w32 + wi] = m;
-        if (L) {
-            const uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
-            uint32_t st = m & ~((m << 1) | prev);
-            while (st) {
-                const int bpos = __ffs(st) - 1;
-                st &= st - 1;
-                const int idx = y * w + (wi << 5) + bpos;
-                L[idx] = idx;
+    for (int y = y0 + ty; y < yend; y += 4) {
+        const uint32_t *row = bufA + (y - rbase) * w32;
+        for (int wi = tx; wi < w32; wi += 64) {
+            const uint32_t m = row[wi];
+            fdst[(size_t)y * w32 + wi] = m;
+            if (L) {
+                const uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
+                uint32_t st = m & ~((m << 1) | prev);
+                while (st) {
+                    const int bpos = __ffs(st) - 1;
+                    st &= st - 1;
+                    const int idx = y * w + (wi << 5) + bpos;
+                    L[idx] = idx;
+                }
             }
         }
     }
@@ -370,7 +424,7 @@ bool morph_fused_supported(int w, const RowSpans *se, int count)
         int a = se[k].anchor, b = se[k].ksize - 1 - se[k].anchor;
         reach += a > b ? a : b;
     }
-    size_t lds = 2 * (size_t)(kBandRows + 2 * reach) * words_per_row(w) * sizeof(uint32_t);
+    size_t lds = 3 * (size_t)(kBandRows + 2 * reach) * words_per_row(w) * sizeof(uint32_t);
     return reach <= 16 && lds <= 64 * 1024;
 }
 
@@ -391,7 +445,7 @@ int launch_morph_fused(const uint32_t *src, uint32_t *dst, int32_t *labels_init,
     }
     const int w32 = words_per_row(w);
     const int nbands = cdiv(h, kBandRows);
-    const size_t lds = 2 * (size_t)(kBandRows + 2 * seq.reach_total) * w32 * sizeof(uint32_t);
+    const size_t lds = 3 * (size_t)(kBandRows + 2 * seq.reach_total) * w32 * sizeof(uint32_t);
     morph_fused_kernel<<<nbands * n, kBlock, lds, st>>>(src, dst, labels_init, h, w, w32, nbands,
                                                        seq);
     VA_LAUNCH_CHECK("morph_fused_kernel");
