@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3_1080p_full_chain", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override frames per step per GPU")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames in the CPU baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=160, help="frames in the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,6 +135,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from video.engine import FrameEngine
+    from video.sharding import gather_counts
 
     w, h, batch, sigma, thresh, morph, blobs, salt = WORKLOADS[args.workload]
     if args.batch > 0:
@@ -142,7 +143,6 @@ def main():
     frames = synth_batch(torch, device, w, h, batch, blobs, salt, seed=3 + rank)
     labels = torch.empty((batch, h, w), dtype=torch.int32, device=device)
     counts = torch.zeros((batch,), dtype=torch.int32, device=device)
-    all_counts = torch.zeros((world * batch,), dtype=torch.int32, device=device) if world > 1 else counts
     steps_morph = (("dilate", "rect", morph), ("erode", "rect", morph)) if morph else ()
     eng = FrameEngine(size=(w, h), max_batch=batch, background="mean", sigma=sigma, thresh=thresh,
                       morphology=steps_morph, connectivity=4, device=local_rank)
@@ -152,7 +152,8 @@ def main():
         eng.run_device(frames.data_ptr(), batch, None, None, labels.data_ptr(), counts.data_ptr(),
                        None, stream.cuda_stream)
         if world > 1:       # the path's only exchange: object counts of every shard, RCCL over xGMI
-            dist.all_gather_into_tensor(all_counts, counts)
+            return gather_counts(counts, world * batch)
+        return counts
 
     def fence():
         torch.cuda.synchronize(device)
