@@ -16,7 +16,9 @@ __global__ void k(uint32_t *out, uint32_t a, uint32_t b)
         for (int i = 0; i < 8; i++) {
             if (MODE == 0) acc[i] = __builtin_amdgcn_udot4(x, y, acc[i], false);
             if (MODE == 1) acc[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x), __builtin_bit_cast(us2, y), acc[i], false);
-            if (MODE == 2) acc[i] = (x & 0xffffffu) * (y & 0xffffffu) + acc[i];
+            if (MODE == 2) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y));
+            if (MODE == 5) asm volatile("v_pk_mad_u16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y));
+            if (MODE == 6) asm volatile("v_add_u32 %0, %1, %0" : "+v"(acc[i]) : "v"(x));
             if (MODE == 3) { float f = __builtin_bit_cast(float, acc[i]); f = __builtin_fmaf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y), f); acc[i] = __builtin_bit_cast(uint32_t, f); }
             if (MODE == 4) acc[i] = (acc[i] | x) + y;   // generic int ops (v_or + v_add or v_add3)
         }
@@ -43,6 +45,6 @@ template <int MODE> void run(const char *name, uint32_t *d)
 int main()
 {
     uint32_t *d; hipMalloc(&d, 256 * 8 * 256 * 4);
-    run<3>("v_fma_f32", d); run<2>("v_mad_u32_u24", d); run<0>("v_dot4_u32_u8", d); run<1>("v_dot2_u32_u16", d); run<4>("int or+add", d);
+    run<3>("v_fma_f32", d); run<2>("v_mad_u32_u24", d); run<0>("v_dot4_u32_u8", d); run<1>("v_dot2_u32_u16", d); run<4>("int or+add (2 instr)", d); run<5>("v_pk_mad_u16", d); run<6>("v_add_u32", d);
     return 0;
 }

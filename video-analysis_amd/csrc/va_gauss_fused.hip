@@ -59,7 +59,7 @@ struct FusedWeights {
     uint32_t wo[17];      // (tap[2j-1], tap[2j]) pairs for odd output rows
 };
 
-template <int TW, int RP>
+template <int TW, int RP, bool HAS_DST, bool HAS_BITS>
 __global__ void __launch_bounds__(TW)
 gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                    uint32_t *__restrict__ bits, int thresh, int h, int w, int w32, int nstrips,
@@ -210,15 +210,15 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
 #pragma unroll
             for (int i = 0; i < kRows; i++) {
                 const uint32_t v = (acc[i] + 32768u) >> 16;
-                if (dst && xin && y0 + i < h)
+                if (HAS_DST && xin && y0 + i < h)
                     dst[((size_t)f * h + y0 + i) * w + x] = (uint8_t)v;
-                if (bits) {
+                if (HAS_BITS) {
                     const unsigned long long b = __ballot(xin && (int)v > thresh);
                     const uint32_t half = (lane & 1) ? (uint32_t)(b >> 32) : (uint32_t)b;
                     myword = (lane >> 1) == i ? half : myword;
                 }
             }
-            if (bits) {
+            if (HAS_BITS) {
                 const int wi = (X0 >> 5) + wave * 2 + (lane & 1);
                 const int yy = y0 + (lane >> 1);
                 if (lane < 2 * kRows && yy < h && wi < w32)
@@ -279,12 +279,25 @@ int launch_tw(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int 
     const int nstrips = cdiv(w, TW);
     const int w32 = words_per_row(w);
     dim3 grid((unsigned)(nstrips * n));
+#define VA_GF_LAUNCH(RPV, D, B)                                                                  \
+    gauss_fused_kernel<TW, RPV, D, B><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt)
+#define VA_GF_RP(RPV)                                      \
+    do {                                                   \
+        if (dst && bits)                                   \
+            VA_GF_LAUNCH(RPV, true, true);                 \
+        else if (dst)                                      \
+            VA_GF_LAUNCH(RPV, true, false);                \
+        else                                               \
+            VA_GF_LAUNCH(RPV, false, true);                \
+    } while (0)
     if (RP == 4)
-        gauss_fused_kernel<TW, 4><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt);
+        VA_GF_RP(4);
     else if (RP == 8)
-        gauss_fused_kernel<TW, 8><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt);
+        VA_GF_RP(8);
     else
-        gauss_fused_kernel<TW, 16><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt);
+        VA_GF_RP(16);
+#undef VA_GF_RP
+#undef VA_GF_LAUNCH
     VA_LAUNCH_CHECK("gauss_fused_kernel");
     return VA_OK;
 }
