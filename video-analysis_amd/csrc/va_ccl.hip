@@ -27,6 +27,7 @@ namespace {
 
 constexpr int kBlock = 256;            // 4 waves
 constexpr int kRowsPerBlock = kBlock / kWave;
+constexpr bool kNtStores = true;   // label image is write-once streaming output
 
 __device__ __forceinline__ int ld_agent(const int32_t *p)
 {
@@ -424,7 +425,12 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                     }
                 }
                 if (vec_ok && x + 3 < w) {
-                    *reinterpret_cast<int4 *>(out + x) = make_int4(v[0], v[1], v[2], v[3]);
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    v4i val = {v[0], v[1], v[2], v[3]};
+                    if (kNtStores)
+                        __builtin_nontemporal_store(val, reinterpret_cast<v4i *>(out + x));
+                    else
+                        *reinterpret_cast<v4i *>(out + x) = val;
                 } else {
                     for (int j = 0; j < 4 && x + j < w; j++)
                         out[x + j] = v[j];

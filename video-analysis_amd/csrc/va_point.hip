@@ -72,19 +72,19 @@ bg_mean_u8_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff
 // ---- cumulative mean, division-free inner loop ---------------------------------------------
 // Per frame the divisor d = n+1 is the same for every pixel, so both quotients of
 //     mean*n/(n+1) + frame/(n+1)
-// are computed as  q0 = x*y;  q = fma(fma(-q0,d,x), y, q0)  twice, with y = RN(1/d) divided once
-// per frame.  By Markstein's theorem (y correctly rounded, quotient faithful after the first
-// correction, FMA residual exact) the result is the correctly rounded quotient, i.e. it is
-// bit-identical to IEEE division; checked exhaustively for frame/(n+1) (all 256 values, every
-// n+1 <= 2^24) and on 1.6e9 random (mean*n, n+1) pairs on the CPU, and against the oracle's
-// plain divisions in tests/test_gpu_parity.py.  It replaces two ~30-instruction float64
-// division sequences per pixel by ten FMA-class operations.
+// are computed as  q0 = RN(x*y);  r = fma(-q0,d,x) (exact);  q = RN(q0 + r*y)  with y = RN(1/d)
+// divided once per frame.  This is the final step of Markstein's division algorithm (IBM
+// RS/6000, Itanium): with a correctly rounded reciprocal the result is the correctly rounded
+// quotient, i.e. bit-identical to IEEE division (the exceptional divisors have an all-ones
+// significand, impossible for an integer n+1 < 2^53).  Checked on the CPU exhaustively for
+// frame/(n+1) (all 256 values x every n+1 <= 2^24, plus random n+1 < 2^45) and on 1.6e9 random
+// (mean*n, n+1) pairs, and on the GPU against the oracle's plain divisions
+// (tests/test_gpu_parity.py).  It replaces two ~30-instruction float64 division sequences per
+// pixel by six FMA-class operations.
 __device__ __forceinline__ double div_by_uniform(double x, double d, double y)
 {
-    double q = x * y;
-    double r = fma(-q, d, x);
-    q = fma(r, y, q);
-    r = fma(-q, d, x);
+    const double q = x * y;
+    const double r = fma(-q, d, x);
     return fma(r, y, q);
 }
 
@@ -100,11 +100,14 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
 #pragma unroll
     for (int k = 0; k < V; k++)
         m[k] = mean[i0 + k];
-    uint2 cur = *reinterpret_cast<const uint2 *>(frames + i0);
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    // frames and differences are one-touch streams: non-temporal loads/stores keep them out of L2
+    v2u cur = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(frames + i0));
     for (int f = 0; f < n; f++) {
-        uint2 nxt = cur;
+        v2u nxt = cur;
         if (f + 1 < n)   // prefetch the next frame's pixels behind this frame's arithmetic
-            nxt = *reinterpret_cast<const uint2 *>(frames + (size_t)(f + 1) * px + i0);
+            nxt = __builtin_nontemporal_load(
+                reinterpret_cast<const v2u *>(frames + (size_t)(f + 1) * px + i0));
         uint8_t p[V], o[V];
         memcpy(p, &cur, 8);
         const double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
@@ -116,9 +119,9 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
             m[k] = div_by_uniform(m[k] * dn, dn1, y) + div_by_uniform(fr, dn1, y);
         }
         if (diff) {
-            uint2 v;
+            v2u v;
             memcpy(&v, o, 8);
-            *reinterpret_cast<uint2 *>(diff + (size_t)f * px + i0) = v;
+            __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(diff + (size_t)f * px + i0));
         }
         cur = nxt;
     }
