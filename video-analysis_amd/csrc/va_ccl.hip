@@ -29,26 +29,45 @@ constexpr int kBlock = 256;            // 4 waves
 constexpr int kRowsPerBlock = kBlock / kWave;
 constexpr bool kNtStores = true;   // label image is write-once streaming output
 
-__device__ __forceinline__ int ld_agent(const int32_t *p)
+// Forest loads/stores that the compiler may not cache in registers but the hardware may serve
+// from L1/L2 (workgroup scope): a stale value is always an OLDER parent of the node, i.e. still
+// an ancestor with a smaller index (parents only decrease), so walks terminate and unions stay
+// correct -- the one place that needs the truth is the linking atomicMin itself, whose return
+// value tells whether the node really was a root (see unite).  Serving the walks from cache
+// instead of agent-scope (memory-side) loads is worth ~2x on the sparse passes.
+__device__ __forceinline__ int ld_forest(const int32_t *p)
 {
-    // relaxed agent-scope load: bypasses the (non-coherent) per-CU L1 so that parents written
-    // by atomics from other CUs / XCDs are observed; also stops the compiler caching it.
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void st_forest(int32_t *p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// root of `a` with path halving. Parents only ever decrease (atomicMin), so a stale read is
-// still an ancestor and the walk terminates at a node with L[r] == r.
+// root of `a` with path halving (plain stores: any ancestor is a valid parent)
 __device__ int find_root(int32_t *L, int a)
 {
     for (;;) {
-        int p = ld_agent(L + a);
+        int p = ld_forest(L + a);
         if (p == a)
             return a;
-        int gp = ld_agent(L + p);
+        int gp = ld_forest(L + p);
         if (gp == p)
             return p;
-        atomicMin(L + a, gp);
+        st_forest(L + a, gp);
         a = gp;
+    }
+}
+
+// read-only walk for the flatten pass: there every run writes its own final root, and a
+// concurrent halving store from a passing walker could overwrite it with a mere ancestor
+__device__ int find_root_ro(const int32_t *L, int a)
+{
+    for (;;) {
+        int p = ld_forest(L + a);
+        if (p == a)
+            return a;
+        a = p;
     }
 }
 
@@ -123,20 +142,54 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     return v;
 }
 
+// The sparse passes (init / link / flatten / rank) map a wave onto EIGHT consecutive rows:
+// lane = (row = lane & 7, word group = lane >> 3), each lane walks a contiguous span of the
+// row's words.  Compared with one row per wave this cuts the number of waves 8x and, more
+// importantly, puts the unions of vertically adjacent runs (the same word column on
+// consecutive rows -- blob edges) on different lanes, so their dependent load/atomic chains run
+// in parallel instead of one after the other.
+constexpr int kRowsPerWave = 8;
+constexpr int kSparseRowsPerBlock = kRowsPerWave * (kBlock / kWave);   // 32
+
+struct SpanCtx {
+    bool valid;      // this lane has a row and a non-empty word span
+    int lane, f, y;
+    size_t row;      // f*h + y
+    int w0, w1;      // word span [w0, w1)
+};
+
+__device__ __forceinline__ SpanCtx span_ctx(int h, int w32, size_t total_rows)
+{
+    SpanCtx c;
+    c.lane = threadIdx.x & (kWave - 1);
+    c.row = (size_t)blockIdx.x * kSparseRowsPerBlock + (size_t)(threadIdx.x >> 6) * kRowsPerWave +
+            (c.lane & (kRowsPerWave - 1));
+    const int g = c.lane >> 3, G = (w32 + 7) >> 3;
+    c.w0 = g * G;
+    c.w1 = min(w32, c.w0 + G);
+    const bool has_row = c.row < total_rows;
+    c.valid = has_row && c.w0 < c.w1;
+    const size_t r = has_row ? c.row : 0;
+    c.f = (int)(r / h);
+    c.y = (int)(r % h);
+    return c;
+}
+
 // ---- K1: every run's first pixel becomes a singleton tree ---------------------------------
 __global__ void __launch_bounds__(kBlock)
 ccl_init_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
                 int w32, size_t total_rows)
 {
-    RowCtx c = row_ctx(h, total_rows);
+    const SpanCtx c = span_ctx(h, w32, total_rows);
     if (!c.valid)
         return;
     const uint32_t *row = bits + c.row * w32;
     int32_t *L = labels + (size_t)c.f * h * w;
-    for (int wi = c.lane; wi < w32; wi += kWave) {
-        uint32_t m = row[wi];
-        uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
+    uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
+    for (int wi = c.w0; wi < c.w1; wi++) {
+        const uint32_t m = row[wi];
         uint32_t s = m & ~((m << 1) | prev);
+        prev = m >> 31;
         while (s) {
             int b = __ffs(s) - 1;
             s &= s - 1;
@@ -152,16 +205,16 @@ __global__ void __launch_bounds__(kBlock)
 ccl_link_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
                 int w32, size_t total_rows)
 {
-    RowCtx c = row_ctx(h, total_rows);
+    const SpanCtx c = span_ctx(h, w32, total_rows);
     if (!c.valid || c.y == 0)
         return;
     const uint32_t *row = bits + c.row * w32;
     const uint32_t *up = row - w32;
     int32_t *L = labels + (size_t)c.f * h * w;
     const int base = c.y * w, ubase = (c.y - 1) * w;
-    for (int wi = c.lane; wi < w32; wi += kWave) {
+    uint32_t mp = c.w0 > 0 ? row[c.w0 - 1] : 0u, upv = c.w0 > 0 ? up[c.w0 - 1] : 0u;
+    for (int wi = c.w0; wi < c.w1; wi++) {
         const uint32_t m = row[wi], u = up[wi];
-        const uint32_t mp = wi > 0 ? row[wi - 1] : 0u, upv = wi > 0 ? up[wi - 1] : 0u;
         // vertical contacts: one union per maximal run of (m & u)
         uint32_t v = m & u;
         uint32_t vs = v & ~((v << 1) | ((mp & upv) >> 31));
@@ -194,6 +247,8 @@ ccl_link_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
                 unite(L, base + x, ubase + run_start(up, x - 1));
             }
         }
+        mp = m;
+        upv = u;
     }
 }
 
@@ -202,29 +257,33 @@ __global__ void __launch_bounds__(kBlock)
 ccl_flatten_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
                    int32_t *__restrict__ row_cnt, int h, int w, int w32, size_t total_rows)
 {
-    RowCtx c = row_ctx(h, total_rows);
-    if (!c.valid)
-        return;
-    const uint32_t *row = bits + c.row * w32;
-    int32_t *L = labels + (size_t)c.f * h * w;
+    const SpanCtx c = span_ctx(h, w32, total_rows);
     int cnt = 0;
-    for (int wi = c.lane; wi < w32; wi += kWave) {
-        uint32_t m = row[wi];
-        uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
-        uint32_t s = m & ~((m << 1) | prev);
-        while (s) {
-            int b = __ffs(s) - 1;
-            s &= s - 1;
-            int idx = c.y * w + (wi << 5) + b;
-            int r = find_root(L, idx);
-            if (r == idx)
-                cnt++;
-            else
-                __hip_atomic_store(L + idx, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c.valid) {
+        const uint32_t *row = bits + c.row * w32;
+        int32_t *L = labels + (size_t)c.f * h * w;
+        uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
+        for (int wi = c.w0; wi < c.w1; wi++) {
+            const uint32_t m = row[wi];
+            uint32_t s = m & ~((m << 1) | prev);
+            prev = m >> 31;
+            while (s) {
+                int b = __ffs(s) - 1;
+                s &= s - 1;
+                int idx = c.y * w + (wi << 5) + b;
+                int r = find_root_ro(L, idx);
+                if (r == idx)
+                    cnt++;
+                else
+                    st_forest(L + idx, r);
+            }
         }
     }
-    cnt = wave_sum(cnt);
-    if (c.lane == 0)
+    // sum over the 8 word groups of each row (lanes with equal lane & 7)
+    cnt += __shfl_xor(cnt, 8, kWave);
+    cnt += __shfl_xor(cnt, 16, kWave);
+    cnt += __shfl_xor(cnt, 32, kWave);
+    if (c.lane < kRowsPerWave && c.row < total_rows)
         row_cnt[c.row] = cnt;
 }
 
@@ -265,36 +324,49 @@ __global__ void __launch_bounds__(kBlock)
 ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
                 const int32_t *__restrict__ row_off, int h, int w, int w32, size_t total_rows)
 {
-    RowCtx c = row_ctx(h, total_rows);
-    if (!c.valid)
-        return;
-    const uint32_t *row = bits + c.row * w32;
+    const SpanCtx c = span_ctx(h, w32, total_rows);
+    const uint32_t *row = bits + (c.row < total_rows ? c.row : 0) * w32;
     int32_t *L = labels + (size_t)c.f * h * w;
-    int base = row_off[c.row];
-    for (int w0 = 0; w0 < w32; w0 += kWave) {
-        const int wi = w0 + c.lane;
-        uint32_t roots = 0;
-        if (wi < w32) {
-            uint32_t m = row[wi];
-            uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
+    // pass 1: roots in this lane's span
+    int nroots = 0;
+    if (c.valid) {
+        uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
+        for (int wi = c.w0; wi < c.w1; wi++) {
+            const uint32_t m = row[wi];
             uint32_t s = m & ~((m << 1) | prev);
+            prev = m >> 31;
             while (s) {
                 int b = __ffs(s) - 1;
                 s &= s - 1;
                 int idx = c.y * w + (wi << 5) + b;
-                if (L[idx] == idx)
-                    roots |= 1u << b;
+                nroots += L[idx] == idx;
             }
         }
-        const int nroots = __popc(roots);
-        const int incl = wave_incl_scan(nroots, c.lane);
-        int k = base + incl - nroots;
-        while (roots) {
-            int b = __ffs(roots) - 1;
-            roots &= roots - 1;
-            L[c.y * w + (wi << 5) + b] = -(++k);
+    }
+    // exclusive prefix over the row's word groups (lanes lane&7, lane&7 + 8, ...)
+    int incl = nroots;
+#pragma unroll
+    for (int o = 8; o < kWave; o <<= 1) {
+        int t = __shfl_up(incl, o, kWave);
+        if (c.lane >= o)
+            incl += t;
+    }
+    if (!c.valid)
+        return;
+    int k = row_off[c.row] + incl - nroots;
+    // pass 2: number them (roots still hold L[idx] == idx: only this lane rewrites its span)
+    uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
+    for (int wi = c.w0; wi < c.w1; wi++) {
+        const uint32_t m = row[wi];
+        uint32_t s = m & ~((m << 1) | prev);
+        prev = m >> 31;
+        while (s) {
+            int b = __ffs(s) - 1;
+            s &= s - 1;
+            int idx = c.y * w + (wi << 5) + b;
+            if (L[idx] == idx)
+                L[idx] = -(++k);
         }
-        base += __shfl(incl, kWave - 1, kWave);
     }
 }
 
@@ -568,26 +640,27 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     VA_REQUIRE(ws_bytes >= 2 * up(total_rows * sizeof(int32_t)), "label: workspace too small");
     int32_t *row_cnt = (int32_t *)workspace;
     int32_t *row_off = (int32_t *)((char *)workspace + up(total_rows * sizeof(int32_t)));
-    const int grid = cdiv((long long)total_rows, kRowsPerBlock);
+    const int grid = cdiv((long long)total_rows, kRowsPerBlock);          // paint: wave = row
+    const int sgrid = cdiv((long long)total_rows, kSparseRowsPerBlock);   // sparse: wave = 8 rows
 
     if (!forest_ready) {
-        ccl_init_kernel<<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+        ccl_init_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
         VA_LAUNCH_CHECK("ccl_init_kernel");
         VA_MARK("ccl_init");
     }
     if (connectivity == 8)
-        ccl_link_kernel<true><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+        ccl_link_kernel<true><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
     else
-        ccl_link_kernel<false><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+        ccl_link_kernel<false><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
     VA_LAUNCH_CHECK("ccl_link_kernel");
     VA_MARK("ccl_link");
-    ccl_flatten_kernel<<<grid, kBlock, 0, st>>>(bits, labels, row_cnt, h, w, w32, total_rows);
+    ccl_flatten_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_cnt, h, w, w32, total_rows);
     VA_LAUNCH_CHECK("ccl_flatten_kernel");
     VA_MARK("ccl_flatten");
     ccl_rowscan_kernel<<<n, kBlock, 0, st>>>(row_cnt, row_off, counts, h);
     VA_LAUNCH_CHECK("ccl_rowscan_kernel");
     VA_MARK("ccl_rowscan");
-    ccl_rank_kernel<<<grid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, total_rows);
+    ccl_rank_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, total_rows);
     VA_LAUNCH_CHECK("ccl_rank_kernel");
     VA_MARK("ccl_rank");
     const int vec = (w % 4 == 0) && aligned(labels, 16);
