@@ -422,6 +422,34 @@ def test_pipeline_variants(oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("h,w", [(70, 96), (45, 4160), (131, 2000)])
+def test_pipeline_morphology_chains(oracle, h, w):
+    """every kernel behind FilterMorphology inside the pipeline: register-streaming (rect, one or
+    two ops, several word chunks per row), LDS-fused (other shapes / longer chains)"""
+    rng = np.random.default_rng(h * w)
+    img = (rng.random((3, h, w)) < 0.35) * np.uint8(200)
+    img[:, :, -3:] = 200                       # foreground touching the right frame border
+    img[:, 0, :] = 200
+    chains = [[("dilate", "rect", 5)], [("erode", "rect", 3)], [("erode", "rect", 7)],
+              [("erode", "rect", 3), ("dilate", "rect", 7)], [("dilate", "rect", 7), ("erode", "rect", 5)],
+              [("erode", "rect", 5), ("erode", "rect", 3)], [("dilate", "rect", 3), ("dilate", "rect", 3)],
+              [("dilate", "ellipse", 5), ("erode", "cross", 3)],
+              [("dilate", "rect", 3), ("erode", "rect", 3), ("dilate", "rect", 5)],
+              [("erode", "rect", 9)], [("dilate", "rect", 4), ("erode", "rect", 4)]]
+    codes = {"erode": oracle.ERODE, "dilate": oracle.DILATE, "rect": oracle.RECT, "cross": oracle.CROSS,
+             "ellipse": oracle.ELLIPSE}
+    for chain in chains:
+        eng = _engine(size=(w, h), max_batch=3, thresh=100, morphology=chain, connectivity=8)
+        out = eng.run(img, want=("mask", "labels", "counts"))
+        m = oracle.threshold_u8(img, 100)
+        for op, shape, k in chain:
+            m = oracle.morph_u8(m, codes[op], codes[shape], k)
+        rl, rc = oracle.label_batch(m, 8)
+        assert np.array_equal(out["mask"], m), chain
+        assert np.array_equal(out["labels"], rl) and np.array_equal(out["counts"], rc), chain
+        eng.close()
+
+
 def test_pipeline_error_paths():
     from video import _hip
     with pytest.raises(_hip.HipError):
