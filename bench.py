@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override frames per step per GPU")
     ap.add_argument("--cpu-frames", type=int, default=160, help="frames in the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (CPU tensors) only to rehearse the multi-rank "
+                         "control flow on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import numpy as np
@@ -128,11 +131,15 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from video.engine import FrameEngine
     from video.sharding import gather_counts
@@ -145,14 +152,14 @@ def main():
     counts = torch.zeros((batch,), dtype=torch.int32, device=device)
     steps_morph = (("dilate", "rect", morph), ("erode", "rect", morph)) if morph else ()
     eng = FrameEngine(size=(w, h), max_batch=batch, background="mean", sigma=sigma, thresh=thresh,
-                      morphology=steps_morph, connectivity=4, device=local_rank)
+                      morphology=steps_morph, connectivity=4, device=dev_index)
     stream = torch.cuda.current_stream(device)
 
     def step():
         eng.run_device(frames.data_ptr(), batch, None, None, labels.data_ptr(), counts.data_ptr(),
                        None, stream.cuda_stream)
         if world > 1:       # the path's only exchange: object counts of every shard, RCCL over xGMI
-            return gather_counts(counts, world * batch)
+            return gather_counts(counts if args.backend == "nccl" else counts.cpu(), world * batch)
         return counts
 
     def fence():
@@ -161,6 +168,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    if world > 1:                 # communicator set-up is not a step: do it before any timing
+        gather_counts(counts if args.backend == "nccl" else counts.cpu(), world * batch)
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -173,7 +183,7 @@ def main():
     stage = eng.stage_times()
     eng.profile(False)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
