@@ -155,6 +155,23 @@ int va_largest_region(const int32_t *labels_dev, const int32_t *counts_dev,
                       int32_t *largest_dev, int64_t *largest_area_dev, uint8_t *mask_out_dev,
                       void *stream);
 
+/* ------------------------------------------------------------------ A8 contour of the largest region
+ * replaces  contours = cv2.findContours(mask.astype(np.uint8), cv2.RETR_EXTERNAL,
+ *                                       cv2.CHAIN_APPROX_SIMPLE)[1]
+ *           contour_id = np.argmax([cv2.contourArea(c) for c in contours])
+ *           get_contour_from_largest_region, video/analysis/regions.py:178-197
+ * 8-connected foreground (any non-zero byte), Suzuki-Abe outer border following from each
+ * component's first raster pixel, points kept only where the direction changes, OpenCV's
+ * most-recent-first contour order for the argmax tie rule.
+ * points_dev: (n, max_points, 2) int32 (x, y); npoints_dev[f] = points of the winning contour
+ * (if > max_points only the first max_points were stored); area_dev[f] = cv2.contourArea of it;
+ * ncomponents_dev[f] = number of 8-connected components (0 -> "Could not find any contour"). */
+size_t va_contour_workspace_bytes(int n, int h, int w);
+int va_largest_contour(const uint8_t *mask_dev, int n, int h, int w, int32_t *points_dev,
+                       int max_points, int32_t *npoints_dev, double *area_dev,
+                       int32_t *ncomponents_dev, void *workspace_dev, size_t workspace_bytes,
+                       void *stream);
+
 /* ------------------------------------------------------------------ fused pipeline
  * One handle per filter chain (not thread-safe; the reference's pull model is single-threaded,
  * video/io/base.py:207-223).  Runs, for a batch of n <= max_batch frames resident in HBM:

@@ -67,6 +67,10 @@ def lib():
         _lib.vao_region_stats.restype = None
         _lib.vao_complete_moments.argtypes = [C.c_void_p, C.c_void_p]
         _lib.vao_complete_moments.restype = None
+        _lib.vao_find_contours_external_simple.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                           C.c_int64, C.c_void_p, C.c_int]
+        _lib.vao_contour_area.argtypes = [C.c_void_p, C.c_int]
+        _lib.vao_contour_area.restype = C.c_double
         _lib.vao_chain_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
@@ -305,6 +309,41 @@ def get_largest_region(mask, ret_area=False, connectivity=4):
     if ret_area:
         return labels == label_max, int(areas[label_max - 1])
     return labels == label_max
+
+
+def find_contours_external_simple(mask):
+    """cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)[1] -> list of (N,1,2) int32
+    arrays in OpenCV's list order (video/analysis/regions.py:180-182)"""
+    m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+    h, w = m.shape
+    cap_pts = 2 * m.size + 16
+    pts = np.zeros((cap_pts, 2), np.int32)
+    sizes = np.zeros(m.size + 1, np.int32)
+    n = lib().vao_find_contours_external_simple(_p(m), h, w, _p(pts), cap_pts, _p(sizes), m.size + 1)
+    if n < 0:
+        raise RuntimeError("contour capacity exceeded")
+    out, o = [], 0
+    for k in range(n):
+        out.append(pts[o:o + sizes[k]].reshape(-1, 1, 2).copy())
+        o += sizes[k]
+    return out
+
+
+def contour_area(contour):
+    """cv2.contourArea (video/analysis/regions.py:188)"""
+    c = np.ascontiguousarray(np.asarray(contour).reshape(-1, 2), np.int32)
+    return lib().vao_contour_area(_p(c), len(c))
+
+
+def get_contour_from_largest_region(mask, ret_area=False):
+    """the reference recipe, video/analysis/regions.py:178-197"""
+    contours = find_contours_external_simple(mask)
+    if not contours:
+        raise RuntimeError("Could not find any contour")
+    areas = [contour_area(c) for c in contours]
+    cid = int(np.argmax(areas))
+    contour = np.squeeze(np.asarray(contours[cid], np.double))
+    return (contour, areas[cid]) if ret_area else contour
 
 
 def chain_u8(frames, sigma, thresh, morph_ksize=0, connectivity=4, mean=None, n_seen=0,

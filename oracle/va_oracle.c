@@ -632,3 +632,147 @@ int vao_chain_u8(const uint8_t *frames, int n, int h, int w, double *mean, int64
     free(lab);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * A8  get_contour_from_largest_region (video/analysis/regions.py:178-197):
+ *         cv2.findContours(mask.astype(np.uint8), cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)[1]
+ *         contour_areas = [cv2.contourArea(cnt) for cnt in contours]; np.argmax
+ * Restatement of OpenCV's Suzuki-Abe scanner (cvFindNextContour / icvFetchContour, OpenCV >= 3.2
+ * semantics: the image is padded with a zero border, nothing is clipped) for 8-bit input,
+ * mode RETR_EXTERNAL, method CHAIN_APPROX_SIMPLE.  PARITY UNPINNED against cv2 itself (not
+ * installed); property-checked in tests/ (points lie on region borders, polygon area vs pixel
+ * count) and used as the independent checker of the GPU's label-root based tracing.
+ * Contours are returned in OpenCV's list order (most recently found first).
+ * out_points: flat (x,y) pairs of all contours in that order; out_sizes[k] = points of contour k.
+ * returns the number of contours, or -1 when a capacity is exceeded.
+ * ---------------------------------------------------------------------------------- */
+static const int kCodeDx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+static const int kCodeDy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+int vao_find_contours_external_simple(const uint8_t *mask, int h, int w, int32_t *out_points,
+                                      int64_t cap_points, int32_t *out_sizes, int cap_contours)
+{
+    const int step = w + 2;
+    signed char *img = (signed char *)calloc((size_t)(h + 2) * step, 1);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            img[(size_t)(y + 1) * step + x + 1] = mask[(size_t)y * w + x] ? 1 : 0;
+    int deltas[16];
+    for (int k = 0; k < 8; k++)
+        deltas[k] = deltas[k + 8] = kCodeDy[k] * step + kCodeDx[k];
+    /* discovery order first; reversed at the end */
+    int ncont = 0;
+    int64_t npts = 0;
+    int64_t *starts = (int64_t *)malloc(sizeof(int64_t) * (size_t)(cap_contours + 1));
+    const signed char nbd = 2;
+    for (int y = 1; y <= h; y++) {
+        int lnbd_x = 0;
+        int prev = 0;
+        signed char *row = img + (size_t)y * step;
+        for (int x = 1; x <= w + 1; x++) {
+            int p = row[x];
+            if (p == prev)
+                continue;
+            int is_hole = 0;
+            if (!(prev == 0 && p == 1)) {
+                if (p != 0 || prev < 1)
+                    goto resume_scan;
+                if (prev & -2)
+                    lnbd_x = x - 1;
+                is_hole = 1;
+            }
+            if (is_hole || row[lnbd_x] > 0)   /* RETR_EXTERNAL */
+                goto resume_scan;
+            {
+                /* icvFetchContour at (x, y), CHAIN_APPROX_SIMPLE */
+                if (ncont >= cap_contours) {
+                    free(img);
+                    free(starts);
+                    return -1;
+                }
+                starts[ncont] = npts;
+                signed char *i0 = row + x, *i1, *i3, *i4 = 0;
+                int ptx = x - 1, pty = y - 1;   /* un-padded coordinates */
+                int s_end = 4, s = 4, prev_s;
+                do {
+                    s = (s - 1) & 7;
+                    i1 = i0 + deltas[s];
+                } while (*i1 == 0 && s != s_end);
+                if (s == s_end) { /* single pixel */
+                    *i0 = (signed char)(nbd | -128);
+                    if (npts + 1 > cap_points) { free(img); free(starts); return -1; }
+                    out_points[2 * npts] = ptx;
+                    out_points[2 * npts + 1] = pty;
+                    npts++;
+                } else {
+                    i3 = i0;
+                    prev_s = s ^ 4;
+                    for (;;) {
+                        s_end = s;
+                        while (s < 15) {
+                            i4 = i3 + deltas[++s];
+                            if (*i4 != 0)
+                                break;
+                        }
+                        s &= 7;
+                        if ((unsigned)(s - 1) < (unsigned)s_end)
+                            *i3 = (signed char)(nbd | -128);
+                        else if (*i3 == 1)
+                            *i3 = nbd;
+                        if (s != prev_s) {
+                            if (npts + 1 > cap_points) { free(img); free(starts); return -1; }
+                            out_points[2 * npts] = ptx;
+                            out_points[2 * npts + 1] = pty;
+                            npts++;
+                            prev_s = s;
+                        }
+                        ptx += kCodeDx[s];
+                        pty += kCodeDy[s];
+                        if (i4 == i0 && i3 == i1)
+                            break;
+                        i3 = i4;
+                        s = (s + 4) & 7;
+                    }
+                }
+                ncont++;
+                lnbd_x = x;
+                p = row[x];
+            }
+        resume_scan:
+            prev = p;
+            if (prev & -2)
+                lnbd_x = x;
+        }
+    }
+    starts[ncont] = npts;
+    /* reverse the contour order in place (OpenCV inserts each new contour at the list head) */
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)(npts ? npts : 1));
+    memcpy(tmp, out_points, sizeof(int32_t) * 2 * (size_t)npts);
+    int64_t o = 0;
+    for (int k = ncont - 1, j = 0; k >= 0; k--, j++) {
+        int64_t n = starts[k + 1] - starts[k];
+        memcpy(out_points + 2 * o, tmp + 2 * starts[k], sizeof(int32_t) * 2 * (size_t)n);
+        out_sizes[j] = (int32_t)n;
+        o += n;
+    }
+    free(tmp);
+    free(img);
+    free(starts);
+    return ncont;
+}
+
+/* cv2.contourArea(contour) (oriented = false) on integer points */
+double vao_contour_area(const int32_t *pts, int n)
+{
+    if (n == 0)
+        return 0.0;
+    double a00 = 0;
+    double px = pts[2 * (n - 1)], py = pts[2 * (n - 1) + 1];
+    for (int i = 0; i < n; i++) {
+        double x = pts[2 * i], y = pts[2 * i + 1];
+        a00 += px * y - py * x;
+        px = x;
+        py = y;
+    }
+    return fabs(a00 * 0.5);
+}

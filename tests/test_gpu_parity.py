@@ -336,6 +336,38 @@ def test_largest_region_and_regionprops(ops, oracle, golden):
     assert 0 <= rp.eccentricity <= 1 and rp.major_axis_length >= rp.minor_axis_length > 0
 
 
+def test_contour_of_largest_region(ops, oracle, golden):
+    """A8 get_contour_from_largest_region: GPU (8-conn label roots + border following) vs the
+    oracle's full Suzuki-Abe scanner, incl. nested components, ties and single pixels"""
+    from video.analysis import regions
+    masks = [golden["mask_" + str(n)] for n in golden["mask_names"]]
+    rng = np.random.default_rng(61)
+    for h, w, d in ((40, 50, 0.2), (64, 200, 0.45), (33, 70, 0.6), (200, 333, 0.52), (17, 4100, 0.4)):
+        masks.append((rng.random((h, w)) < d).astype(np.uint8))
+    yy, xx = np.mgrid[:300, :400]
+    blobs = np.zeros((300, 400), np.uint8)
+    for cx, cy, r in ((60, 70, 30), (200, 150, 55), (330, 230, 40), (200, 150, 20)):
+        blobs |= ((xx - cx) ** 2 + (yy - cy) ** 2 <= r * r).astype(np.uint8)
+    ring = blobs.copy()
+    ring[(xx - 200) ** 2 + (yy - 150) ** 2 <= 35 ** 2] = 0            # hole ...
+    ring[(xx - 200) ** 2 + (yy - 150) ** 2 <= 12 ** 2] = 1            # ... with a nested blob
+    two = np.zeros((40, 60), np.uint8)
+    two[5:15, 5:15] = 1
+    two[25:35, 40:50] = 1                                             # equal areas: tie rule
+    masks += [blobs, ring, two, np.ones((30, 40), np.uint8), np.eye(25, dtype=np.uint8)]
+    for m in masks:
+        if not m.any():
+            with pytest.raises(RuntimeError):
+                regions.get_contour_from_largest_region(m)
+            continue
+        ref, ref_area = oracle.get_contour_from_largest_region(m, ret_area=True)
+        got, area = regions.get_contour_from_largest_region(m, ret_area=True)
+        assert got.dtype == np.float64 and got.shape == ref.shape
+        assert np.array_equal(got, ref) and area == ref_area
+    pts, area, count = ops.largest_contour(two, max_points=2)        # truncated output
+    assert len(pts) == 2 and count == 2
+
+
 # ------------------------------------------------------------------------ fused pipeline
 def _engine(**kw):
     from video.engine import FrameEngine

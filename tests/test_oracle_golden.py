@@ -195,3 +195,61 @@ def test_chain_vectors(golden, oracle):
     m = oracle.morph_u8(oracle.morph_u8(m, oracle.DILATE, oracle.RECT, 5), oracle.ERODE,
                         oracle.RECT, 5)
     assert np.array_equal(m, mask) and np.array_equal(mean, mean2)
+
+
+def test_contours_known_answers_and_properties(golden, oracle):
+    """A8: parity with cv2 itself is unpinned (no OpenCV offline); these pin the restatement
+    to known OpenCV outputs for simple shapes and to geometric invariants."""
+    from scipy import ndimage
+    m = np.zeros((8, 10), np.uint8)
+    m[2:5, 3:7] = 1
+    cs = oracle.find_contours_external_simple(m)
+    # a filled rectangle: OpenCV returns the 4 corners, starting top-left, going down first
+    assert len(cs) == 1 and cs[0].reshape(-1, 2).tolist() == [[3, 2], [3, 4], [6, 4], [6, 2]]
+    assert oracle.contour_area(cs[0]) == 6.0                        # (w-1)*(h-1)
+    m = np.zeros((8, 10), np.uint8)
+    m[1, 1] = m[3, 3] = m[4, 4] = 1
+    m[6, 1:9] = 1
+    cs = [c.reshape(-1, 2).tolist() for c in oracle.find_contours_external_simple(m)]
+    assert cs == [[[1, 6], [8, 6]], [[3, 3], [4, 4]], [[1, 1]]]     # most recently found first
+    ring = np.zeros((12, 12), np.uint8)
+    ring[1:11, 1:11] = 1
+    ring[3:9, 3:9] = 0
+    ring[5:7, 5:7] = 1                                              # blob inside the hole
+    cs = oracle.find_contours_external_simple(ring)
+    assert len(cs) == 1 and cs[0].reshape(-1, 2).tolist() == [[1, 1], [1, 10], [10, 10], [10, 1]]
+    assert oracle.find_contours_external_simple(np.zeros((5, 5), np.uint8)) == []
+    with pytest.raises(RuntimeError):
+        oracle.get_contour_from_largest_region(np.zeros((5, 5), np.uint8))
+    # invariants on the golden masks: one external contour per 8-component that is not nested,
+    # every point is a foreground pixel touching the background (or the frame edge)
+    for name in [str(n) for n in golden["mask_names"]]:
+        mask = golden["mask_" + name]
+        cs = oracle.find_contours_external_simple(mask)
+        assert len(cs) <= int(golden["count8_" + name])
+        pad = np.pad(mask, 1)
+        for c in cs:
+            for x, y in c.reshape(-1, 2):
+                assert mask[y, x]
+                assert pad[y:y + 3, x:x + 3].min() == 0
+        # first points in OpenCV order are the components' first raster pixels, bottom-most first
+        firsts = [(int(c[0, 0, 1]), int(c[0, 0, 0])) for c in cs]
+        assert firsts == sorted(firsts, reverse=True)
+    # filled polygon of the contour == the (hole-filled) component, for blob-like shapes
+    from PIL import Image, ImageDraw
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[:90, :120]
+    for _ in range(10):
+        m = np.zeros((90, 120), bool)
+        for _ in range(4):
+            cx, cy, a, b = rng.uniform(20, 100), rng.uniform(20, 70), rng.uniform(4, 18), rng.uniform(4, 18)
+            m |= ((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 <= 1
+        contour, area = oracle.get_contour_from_largest_region(m, ret_area=True)
+        lab, cnt = ndimage.label(m, np.ones((3, 3)))
+        img = Image.new("L", (120, 90), 0)
+        ImageDraw.Draw(img).polygon([tuple(p) for p in contour.astype(int)], fill=1, outline=1)
+        poly = np.array(img, bool)
+        comp = lab[int(contour[0][1]), int(contour[0][0])]
+        filled = ndimage.binary_fill_holes(lab == comp)
+        assert np.array_equal(poly, filled)
+        assert area <= filled.sum()

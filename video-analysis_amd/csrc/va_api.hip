@@ -366,6 +366,45 @@ int va_largest_region(const int32_t *labels, const int32_t *counts, const int64_
                                  mask_out, as_stream(stream));
 }
 
+// ------------------------------------------------------------------------------ contour
+size_t va_contour_workspace_bytes(int n, int h, int w)
+{
+    if (n <= 0 || h <= 0 || w <= 0)
+        return 256;
+    return ccl_workspace_bytes(n, h, w) + align_up((size_t)n * h * w * sizeof(int32_t)) +
+           align_up((size_t)n * sizeof(unsigned long long));
+}
+
+int va_largest_contour(const uint8_t *mask, int n, int h, int w, int32_t *points, int max_points,
+                       int32_t *npoints, double *area, int32_t *ncomponents, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    VA_REQUIRE(mask && points && npoints && ncomponents && workspace, "va_largest_contour: NULL argument");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0 && max_points > 0, "va_largest_contour: bad shape");
+    VA_REQUIRE(workspace_bytes >= va_contour_workspace_bytes(n, h, w),
+               "va_largest_contour: workspace of %zu bytes < required %zu", workspace_bytes,
+               va_contour_workspace_bytes(n, h, w));
+    if (n == 0)
+        return VA_OK;
+    hipStream_t st = as_stream(stream);
+    char *ws = (char *)workspace;
+    const size_t bits_bytes = align_up((size_t)n * h * words_per_row(w) * sizeof(uint32_t));
+    const size_t rows_bytes = ccl_workspace_bytes(n, h, w) - bits_bytes;
+    uint32_t *bits = (uint32_t *)ws;
+    void *rows = ws + bits_bytes;
+    int32_t *forest = (int32_t *)(ws + bits_bytes + rows_bytes);
+    unsigned long long *keys =
+        (unsigned long long *)((char *)forest + align_up((size_t)n * h * w * sizeof(int32_t)));
+    int rc = launch_pack_bits(mask, bits, n, h, w, 0, st);
+    if (rc)
+        return rc;
+    rc = launch_ccl(bits, forest, ncomponents, n, h, w, 8, rows, rows_bytes, nullptr, 0, st, nullptr,
+                    false, /*paint=*/false);
+    if (rc)
+        return rc;
+    return launch_largest_contour(bits, forest, n, h, w, keys, points, max_points, npoints, area, st);
+}
+
 // ------------------------------------------------------------------------------ pipeline
 static int pipeline_free(va_pipeline *p)
 {

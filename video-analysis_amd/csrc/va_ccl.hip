@@ -605,6 +605,155 @@ select_label_kernel(const int32_t *__restrict__ labels, const int32_t *__restric
     mask[i] = (lm != 0 && labels[i] == lm) ? 1 : 0;
 }
 
+// ---- A8: outer border following (cv2.findContours RETR_EXTERNAL / CHAIN_APPROX_SIMPLE) -----
+// OpenCV's icvFetchContour walk, started at a component's first raster pixel (= its forest
+// root).  Direction codes: 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE (y grows downwards).
+struct BitImage {
+    const uint32_t *bits;
+    int h, w, w32;
+    __device__ __forceinline__ int at(int x, int y) const
+    {
+        if (x < 0 || x >= w || y < 0 || y >= h)
+            return 0;
+        return (bits[(size_t)y * w32 + (x >> 5)] >> (x & 31)) & 1u;
+    }
+};
+__device__ __forceinline__ int code_dx(int s) { return (0x1 | 0x2 | 0x80) >> s & 1 ? 1 : ((0x8 | 0x10 | 0x20) >> s & 1 ? -1 : 0); }
+__device__ __forceinline__ int code_dy(int s) { return (0x2 | 0x4 | 0x8) >> s & 1 ? -1 : ((0x20 | 0x40 | 0x80) >> s & 1 ? 1 : 0); }
+
+template <class Emit>
+__device__ void trace_outer_border(const BitImage &im, int x0, int y0, Emit &emit)
+{
+    int s_end = 4, s = 4, x1, y1;
+    do {
+        s = (s - 1) & 7;
+        x1 = x0 + code_dx(s);
+        y1 = y0 + code_dy(s);
+    } while (!im.at(x1, y1) && s != s_end);
+    if (s == s_end) {   // single pixel
+        emit(x0, y0);
+        return;
+    }
+    int x3 = x0, y3 = y0, px = x0, py = y0, prev_s = s ^ 4;
+    const long long max_steps = 8ll * im.h * im.w + 16;   // a border visits a pixel at most 8 times
+    for (long long step = 0; step < max_steps; step++) {
+        int x4 = x3, y4 = y3;
+        while (s < 15) {
+            ++s;
+            x4 = x3 + code_dx(s & 7);
+            y4 = y3 + code_dy(s & 7);
+            if (im.at(x4, y4))
+                break;
+        }
+        s &= 7;
+        if (s != prev_s) {   // CHAIN_APPROX_SIMPLE: keep a point only where the direction changes
+            emit(px, py);
+            prev_s = s;
+        }
+        px += code_dx(s);
+        py += code_dy(s);
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1)
+            break;
+        x3 = x4;
+        y3 = y4;
+        s = (s + 4) & 7;
+    }
+}
+
+struct AreaEmit {   // shoelace sum over the emitted points (cv2.contourArea before *0.5 and abs)
+    long long cross = 0;
+    int n = 0, fx = 0, fy = 0, lx = 0, ly = 0;
+    __device__ __forceinline__ void operator()(int x, int y)
+    {
+        if (n == 0) {
+            fx = x;
+            fy = y;
+        } else {
+            cross += (long long)lx * y - (long long)ly * x;
+        }
+        lx = x;
+        ly = y;
+        n++;
+    }
+    __device__ __forceinline__ long long twice_area() const
+    {
+        long long c = cross + ((long long)lx * fy - (long long)ly * fx);   // close the polygon
+        return c < 0 ? -c : c;
+    }
+};
+
+// every component: trace, keep max (contour area, then first-pixel index) per frame.  OpenCV
+// returns the contours most-recent-first, so np.argmax's "first maximum" is the component
+// whose first pixel comes LAST in raster order: the larger index wins ties.
+__global__ void __launch_bounds__(kBlock)
+contour_areas_kernel(const uint32_t *__restrict__ bits, const int32_t *__restrict__ forest,
+                     unsigned long long *__restrict__ best, int h, int w, int w32,
+                     size_t total_rows)
+{
+    const SpanCtx c = span_ctx(h, w32, total_rows);
+    if (!c.valid)
+        return;
+    const uint32_t *row = bits + c.row * w32;
+    const int32_t *L = forest + (size_t)c.f * h * w;
+    BitImage im{bits + (size_t)c.f * h * w32, h, w, w32};
+    uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
+    for (int wi = c.w0; wi < c.w1; wi++) {
+        const uint32_t m = row[wi];
+        uint32_t s = m & ~((m << 1) | prev);
+        prev = m >> 31;
+        while (s) {
+            const int b = __ffs(s) - 1;
+            s &= s - 1;
+            const int x = (wi << 5) + b, idx = c.y * w + x;
+            if (L[idx] >= 0)
+                continue;   // not a component's first pixel
+            AreaEmit e;
+            trace_outer_border(im, x, c.y, e);
+            const unsigned long long key =
+                ((unsigned long long)e.twice_area() << 32) | (unsigned long long)(unsigned)(idx + 1);
+            atomicMax(best + c.f, key);
+        }
+    }
+}
+
+struct PointEmit {
+    int32_t *pts;
+    int cap;
+    AreaEmit a;
+    __device__ __forceinline__ void operator()(int x, int y)
+    {
+        if (a.n < cap) {
+            pts[2 * a.n] = x;
+            pts[2 * a.n + 1] = y;
+        }
+        a(x, y);
+    }
+};
+
+__global__ void contour_points_kernel(const uint32_t *__restrict__ bits,
+                                      const unsigned long long *__restrict__ best, int h, int w,
+                                      int w32, int32_t *__restrict__ points, int max_points,
+                                      int32_t *__restrict__ npoints, double *__restrict__ area)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x != 0)
+        return;
+    const unsigned long long key = best[f];
+    if (key == 0) {
+        npoints[f] = 0;
+        if (area)
+            area[f] = 0.0;
+        return;
+    }
+    const int idx = (int)(key & 0xFFFFFFFFull) - 1;
+    BitImage im{bits + (size_t)f * h * w32, h, w, w32};
+    PointEmit e{points + (size_t)f * max_points * 2, max_points, AreaEmit()};
+    trace_outer_border(im, idx % w, idx / w, e);
+    npoints[f] = e.a.n;
+    if (area)
+        area[f] = 0.5 * (double)e.a.twice_area();
+}
+
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -621,7 +770,7 @@ size_t ccl_workspace_bytes(int n, int h, int w)
 // workspace here = row_cnt + row_off only (the caller owns the bit mask)
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st, StageProfiler *prof, bool forest_ready)
+               hipStream_t st, StageProfiler *prof, bool forest_ready, bool paint)
 {
 #define VA_MARK(nm)      \
     do {                 \
@@ -663,6 +812,8 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     ccl_rank_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, total_rows);
     VA_LAUNCH_CHECK("ccl_rank_kernel");
     VA_MARK("ccl_rank");
+    if (!paint)
+        return VA_OK;
     const int vec = (w % 4 == 0) && aligned(labels, 16);
     if (stats && max_labels > 0) {
         size_t entries = (size_t)n * max_labels;
@@ -721,4 +872,26 @@ int launch_largest_region(const int32_t *labels, const int32_t *counts, const in
     return VA_OK;
 }
 
+}  // namespace va
+
+namespace va {
+int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, int h, int w,
+                           unsigned long long *best_keys, int32_t *points, int max_points,
+                           int32_t *npoints, double *area, hipStream_t st)
+{
+    VA_REQUIRE(bits && forest && best_keys && points && npoints && max_points > 0,
+               "largest_contour: bad argument");
+    if (n == 0)
+        return VA_OK;
+    const int w32 = words_per_row(w);
+    const size_t total_rows = (size_t)n * h;
+    VA_HIP(hipMemsetAsync(best_keys, 0, sizeof(unsigned long long) * n, st));
+    const int sgrid = cdiv((long long)total_rows, 32);
+    contour_areas_kernel<<<sgrid, 256, 0, st>>>(bits, forest, best_keys, h, w, w32, total_rows);
+    VA_LAUNCH_CHECK("contour_areas_kernel");
+    contour_points_kernel<<<n, 64, 0, st>>>(bits, best_keys, h, w, w32, points, max_points, npoints,
+                                          area);
+    VA_LAUNCH_CHECK("contour_points_kernel");
+    return VA_OK;
+}
 }  // namespace va

@@ -145,7 +145,13 @@ int launch_morph_fused(const uint32_t *src, uint32_t *dst, int32_t *labels_init,
 size_t ccl_workspace_bytes(int n, int h, int w);
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st, StageProfiler *prof = nullptr, bool forest_ready = false);
+               hipStream_t st, StageProfiler *prof = nullptr, bool forest_ready = false,
+               bool paint = true);
+// outer contour of the component with the largest contour area (8-connectivity), on a forest
+// prepared by launch_ccl(..., paint = false): roots hold -(label) at their first pixel
+int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, int h, int w,
+                           unsigned long long *best_keys, int32_t *points, int max_points,
+                           int32_t *npoints, double *area, hipStream_t st);
 int launch_stats_from_labels(const int32_t *labels, int n, int h, int w, int max_labels,
                              int64_t *stats, hipStream_t st);
 int launch_largest_region(const int32_t *labels, const int32_t *counts, const int64_t *stats,

@@ -63,3 +63,17 @@ def get_largest_region(mask, ret_area=False, connectivity=4):
     if ret_area:
         return region, area
     return region
+
+
+def get_contour_from_largest_region(mask, ret_area=False):
+    """contour of the region with the largest contour area as an (N, 2) float64 array of (x, y)
+    points -- cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + cv2.contourArea + argmax,
+    reference: video/analysis/regions.py:178-197.  RuntimeError when the mask is empty."""
+    from .. import ops
+    points, area, count = ops.largest_contour(mask)
+    if count == 0:
+        raise RuntimeError("Could not find any contour")
+    contour = np.squeeze(np.asarray(points.reshape(-1, 1, 2), np.double))
+    if ret_area:
+        return contour, area
+    return contour

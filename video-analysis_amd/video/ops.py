@@ -257,3 +257,38 @@ def largest_region(mask, connectivity=4):
     finally:
         for b in bufs:
             b.free()
+
+
+def largest_contour(mask, max_points=None):
+    """outer contour (cv2 RETR_EXTERNAL / CHAIN_APPROX_SIMPLE) of the component with the largest
+    contour area.  returns (points (N,2) int32, area float, number of components)"""
+    m = np.asarray(mask)
+    if m.ndim != 2:
+        raise ValueError("mask must be 2-d")
+    if m.dtype != np.uint8:
+        m = (m != 0).astype(np.uint8)
+    m = np.ascontiguousarray(m)
+    h, w = m.shape
+    L = _hip.lib()
+    cap = int(max_points) if max_points else 4096
+    src = DeviceBuffer.from_array(m)
+    ws_bytes = L.va_contour_workspace_bytes(1, h, w)
+    ws = DeviceBuffer(ws_bytes)
+    npts, area, ncomp = DeviceBuffer(4), DeviceBuffer(8), DeviceBuffer(4)
+    bufs = [src, ws, npts, area, ncomp]
+    try:
+        while True:
+            pts = DeviceBuffer(cap * 8)
+            bufs.append(pts)
+            check(L.va_largest_contour(src.ptr, 1, h, w, pts.ptr, cap, npts.ptr, area.ptr, ncomp.ptr,
+                                       ws.ptr, ws_bytes, None))
+            n = int(npts.download((1,), np.int32)[0])
+            if n <= cap or max_points:
+                break
+            cap = n                       # rare: a very long contour, run again with room for it
+        count = int(ncomp.download((1,), np.int32)[0])
+        points = pts.download((min(n, cap), 2), np.int32)
+        return points, float(area.download((1,), np.float64)[0]), count
+    finally:
+        for b in bufs:
+            b.free()
