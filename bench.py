@@ -38,6 +38,8 @@ WORKLOADS = {
     "cfg4_4k_full_chain": (3840, 2160, 128, 5.0, 20, 5, 160, 0.002),
     "cfg1_480p_small": (640, 480, 64, 2.0, 20, 0, 3, 0.0),
 }
+# BASELINE.json configs[4]: float32 3-channel frames, adaptive (EMA) background + sigma=9 blur
+F32_WORKLOADS = {"cfg5_1080p_f32x3_sigma9": (1920, 1080, 3, 256, 9.0, 0.02)}
 
 # algorithmic (compulsory) bytes per frame-pixel of each stage = every input byte of the stage
 # read once + every output byte written once (DESIGN.md "Kernels"); bits = 1/8 B per pixel
@@ -104,12 +106,49 @@ def cpu_baseline(frames_host, sigma, thresh, morph, sample_frames):
                          os.cpu_count() or 0, dt)}
 
 
+def bench_f32(args, torch, device, dev_index, rank, world):
+    """side workload (not the headline metric): cfg#5 float32 x 3 channels"""
+    import numpy as np
+    from video.engine import FrameEngine
+    w, h, c, batch, sigma, rate = F32_WORKLOADS[args.workload]
+    if args.batch > 0:
+        batch = args.batch
+    g = torch.Generator(device=device)
+    g.manual_seed(5 + rank)
+    frames = torch.rand((batch, h, w, c), generator=g, device=device, dtype=torch.float32)
+    out = torch.empty_like(frames)
+    eng = FrameEngine(size=(w, h), channels=c, dtype=np.float32, max_batch=batch, background="ema",
+                      bg_rate=rate, sigma=sigma, device=dev_index)
+    stream = torch.cuda.current_stream(device)
+    for _ in range(args.warmup):
+        eng.run_device(frames.data_ptr(), batch, out.data_ptr(), None, None, None, None, stream.cuda_stream)
+    torch.cuda.synchronize(device)
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run_device(frames.data_ptr(), batch, out.data_ptr(), None, None, None, None, stream.cuda_stream)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    stage = eng.stage_times()
+    fps = batch * args.steps / dt
+    alg = w * h * c * 4 * 2
+    print(json.dumps({"metric": "frames/sec (EMA bg + sigma=9 blur) 1080p float32x3", "value": round(fps, 2),
+                      "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": args.workload, "engine": eng.description, "batch": batch},
+                      "chain": {"alg_bytes_per_frame": alg, "achieved_GBs": round(alg * fps / 1e9, 1),
+                                "stage_avg_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in stage.items()}}}),
+          flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3_1080p_full_chain", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3_1080p_full_chain",
+                    choices=sorted(WORKLOADS) + sorted(F32_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override frames per step per GPU")
     ap.add_argument("--cpu-frames", type=int, default=160, help="frames in the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,6 +183,8 @@ def main():
     from video.engine import FrameEngine
     from video.sharding import gather_counts
 
+    if args.workload in F32_WORKLOADS:
+        return bench_f32(args, torch, device, dev_index, rank, world)
     w, h, batch, sigma, thresh, morph, blobs, salt = WORKLOADS[args.workload]
     if args.batch > 0:
         batch = args.batch

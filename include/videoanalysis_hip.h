@@ -172,6 +172,27 @@ int va_largest_contour(const uint8_t *mask_dev, int n, int h, int w, int32_t *po
                        int32_t *ncomponents_dev, void *workspace_dev, size_t workspace_bytes,
                        void *stream);
 
+/* ------------------------------------------------------------------ N2 small stencils
+ * replaces  detect_peaks(img, include_plateaus), video/analysis/image.py:267-306:
+ *           ndimage.maximum_filter(img, footprint=8-neighbourhood) == img, minus the
+ *           binary_erosion(img == 0, 8-neighbourhood, border_value=1) background (plateaus), or
+ *           img > maximum over the 8 neighbours.  dst: 0/1 u8 mask. */
+int va_detect_peaks_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w,
+                       int include_plateaus, void *stream);
+/* replaces  the python fallback of mask_thinning, video/analysis/image.py:243-258 (3x3 cross):
+ *           eroded = cv2.erode(img); temp = cv2.dilate(eroded); cv2.subtract(img, temp, temp);
+ *           cv2.bitwise_or(skel, temp, skel); img = eroded   ... until img is empty.
+ * img_dev is consumed (used as ping-pong scratch with scratch_dev); skel_dev receives the
+ * skeleton.  Synchronises the stream once per iteration (the loop's exit test). */
+int va_mask_thinning_u8(uint8_t *img_dev, uint8_t *scratch_dev, uint8_t *skel_dev, int h, int w,
+                        int *iterations_out, void *stream);
+/* replaces  get_image_statistics, video/analysis/image.py:131-201: local mean and variance in a
+ *           (2*ksize+1)^2 box or ellipse window of (img - prior), zero border.
+ * kernel: 0 box, 1 ellipse.  mean_out_dev / var_out_dev: (n,h,w) float64; var_out may be NULL. */
+int va_image_statistics_u8(const uint8_t *src_dev, double *mean_out_dev, double *var_out_dev, int n,
+                           int h, int w, int kernel, int ksize, double prior, int exclude_center,
+                           void *stream);
+
 /* ------------------------------------------------------------------ fused pipeline
  * One handle per filter chain (not thread-safe; the reference's pull model is single-threaded,
  * video/io/base.py:207-223).  Runs, for a batch of n <= max_batch frames resident in HBM:

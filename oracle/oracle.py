@@ -346,6 +346,66 @@ def get_contour_from_largest_region(mask, ret_area=False):
     return (contour, areas[cid]) if ret_area else contour
 
 
+def detect_peaks(img, include_plateaus=True):
+    """LITERAL restatement of detect_peaks (video/analysis/image.py:267-306) with scipy.ndimage"""
+    from scipy import ndimage
+    neighborhood = ndimage.generate_binary_structure(2, 2)
+    if include_plateaus:
+        img_max = ndimage.maximum_filter(img, footprint=neighborhood)
+        local_max = (img == img_max)
+        background = (img == 0)
+        eroded_background = ndimage.binary_erosion(background, structure=neighborhood,
+                                                   border_value=1)
+        return local_max ^ eroded_background       # bool `-` of the reference era == XOR
+    neighborhood[1, 1] = 0
+    img_max = ndimage.maximum_filter(img, footprint=neighborhood)
+    return img > img_max
+
+
+def mask_thinning(img):
+    """python method of mask_thinning (video/analysis/image.py:243-258), cv2 calls replaced by
+    the oracle's own erode/dilate; returns (skeleton, iterations)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    skel = np.zeros(img.shape, np.uint8)
+    it = 0
+    # the reference loops forever on a mask that fills the frame (erosion never shrinks it);
+    # product and oracle both stop after min(h, w)//2 + 3 iterations
+    max_it = min(img.shape) // 2 + 3
+    while True:
+        eroded = morph_u8(img, ERODE, CROSS, 3)
+        temp = morph_u8(eroded, DILATE, CROSS, 3)
+        temp = np.where(img > temp, img - temp, 0).astype(np.uint8)      # cv2.subtract saturates
+        skel |= temp
+        img = eroded
+        it += 1
+        if not img.any() or it >= max_it:
+            break
+    return skel, it
+
+
+def image_statistics(img, kernel="box", ksize=5, prior=None, exclude_center=False):
+    """get_image_statistics (video/analysis/image.py:131-201) with scipy window sums
+    (zero border) in place of cv2.boxFilter / cv2.filter2D; returns (mean, var)"""
+    from scipy import ndimage
+    if prior is None:
+        prior = img.mean()
+    k = 2 * int(ksize) + 1
+    weights = np.ones((k, k)) if kernel == "box" else structuring_element(ELLIPSE, k).astype(float)
+    count = weights.sum()
+    data = img.astype(np.int64) - prior
+    s1 = ndimage.correlate(np.asarray(data, float), weights, mode="constant", cval=0.0)
+    if exclude_center:
+        s1 = s1 - data
+        count -= 1
+    mean = s1 / count + prior
+    d2 = np.square(np.asarray(data, float))
+    s2 = ndimage.correlate(d2, weights, mode="constant", cval=0.0)
+    if exclude_center:
+        s2 = s2 - d2
+    var = (s2 - s1 ** 2 / count) / (count - 1)
+    return mean, var
+
+
 def chain_u8(frames, sigma, thresh, morph_ksize=0, connectivity=4, mean=None, n_seen=0,
              want_mask=True, want_labels=True):
     """bg(mean) -> blur -> threshold -> [dilate,erode k x k] -> label, one batch"""

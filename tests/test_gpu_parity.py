@@ -368,6 +368,42 @@ def test_contour_of_largest_region(ops, oracle, golden):
     assert len(pts) == 2 and count == 2
 
 
+def test_small_stencils_peaks_thinning_statistics(ops, oracle):
+    """N2: detect_peaks / mask_thinning (python method) / get_image_statistics"""
+    from video.analysis import image
+    rng = np.random.default_rng(71)
+    for shape in ((1, 1), (1, 9), (7, 1), (40, 53), (128, 200)):
+        img = rng.integers(0, 6, shape, dtype=np.uint8) * rng.integers(0, 2, shape, dtype=np.uint8)
+        smooth = (rng.integers(0, 256, shape) // 32 * 32).astype(np.uint8)     # plateaus
+        for im in (img, smooth, np.zeros(shape, np.uint8), np.full(shape, 9, np.uint8)):
+            for plateaus in (True, False):
+                got = image.detect_peaks(im, plateaus)
+                assert got.dtype == bool
+                assert np.array_equal(got, oracle.detect_peaks(im, plateaus)), (shape, plateaus)
+    yy, xx = np.mgrid[:90, :130]
+    blob = (((xx - 40) / 30.0) ** 2 + ((yy - 45) / 18.0) ** 2 <= 1) | (abs(xx - 95) + abs(yy - 40) < 25)
+    for m in (blob.astype(np.uint8) * 255, blob.astype(np.uint8), np.zeros((10, 12), np.uint8),
+              np.ones((9, 9), np.uint8), (rng.random((60, 70)) < 0.7).astype(np.uint8) * 255):
+        skel, it = ops.mask_thinning(m)
+        rs, rit = oracle.mask_thinning(m)
+        assert it == rit and np.array_equal(skel, rs)
+        assert np.array_equal(image.mask_thinning(m), rs)
+    img = rng.integers(0, 256, (50, 64), dtype=np.uint8)
+    for kernel in ("box", "ellipse"):
+        for ksize in (1, 2, 5):
+            for excl in (False, True):
+                for prior in (0, 128, None, 100.5):
+                    mean, var = image.get_image_statistics(img, kernel, ksize, prior=prior,
+                                                           exclude_center=excl)
+                    rm, rv = oracle.image_statistics(img, kernel, ksize, prior, excl)
+                    if prior in (0, 128):          # integer data: every window sum is exact
+                        assert np.array_equal(mean, rm) and np.array_equal(var, rv)
+                    else:                          # float prior: summation order may differ
+                        assert np.allclose(mean, rm, rtol=1e-12, atol=1e-9)
+                        assert np.allclose(var, rv, rtol=1e-9, atol=1e-6)
+    assert image.get_image_statistics(img, "box", 3, ret_var=False).shape == img.shape
+
+
 # ------------------------------------------------------------------------ fused pipeline
 def _engine(**kw):
     from video.engine import FrameEngine

@@ -366,6 +366,64 @@ int va_largest_region(const int32_t *labels, const int32_t *counts, const int64_
                                  mask_out, as_stream(stream));
 }
 
+// ------------------------------------------------------------------------------ stencils
+int va_detect_peaks_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int include_plateaus,
+                       void *stream)
+{
+    VA_REQUIRE(src && dst && src != dst, "va_detect_peaks_u8: bad pointers");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_detect_peaks_u8: bad shape");
+    return launch_detect_peaks(src, dst, n, h, w, include_plateaus, as_stream(stream));
+}
+
+int va_mask_thinning_u8(uint8_t *img, uint8_t *scratch, uint8_t *skel, int h, int w,
+                        int *iterations_out, void *stream)
+{
+    VA_REQUIRE(img && scratch && skel, "va_mask_thinning_u8: NULL argument");
+    VA_REQUIRE(h > 0 && w > 0, "va_mask_thinning_u8: bad shape");
+    hipStream_t st = as_stream(stream);
+    void *cnt_dev;
+    int rc = get_scratch(256, &cnt_dev);
+    if (rc)
+        return rc;
+    VA_HIP(hipMemsetAsync(skel, 0, (size_t)h * w, st));
+    uint8_t *cur = img, *nxt = scratch;
+    int it = 0;
+    // a 3x3-cross erosion empties any mask within min(h,w)/2 + 1 steps, except one that fills the
+    // frame (the border never wins): the reference would loop forever there, we stop
+    const int max_it = (h < w ? h : w) / 2 + 2;
+    for (;; it++) {
+        rc = launch_thinning_step(cur, nxt, skel, 1, h, w, (unsigned long long *)cnt_dev, st);
+        if (rc)
+            return rc;
+        unsigned long long nz = 0;
+        VA_HIP(hipMemcpyAsync(&nz, cnt_dev, sizeof(nz), hipMemcpyDeviceToHost, st));
+        VA_HIP(hipStreamSynchronize(st));
+        uint8_t *t = cur;
+        cur = nxt;
+        nxt = t;
+        if (nz == 0 || it >= max_it)
+            break;
+    }
+    if (iterations_out)
+        *iterations_out = it + 1;
+    return VA_OK;
+}
+
+int va_image_statistics_u8(const uint8_t *src, double *mean_out, double *var_out, int n, int h,
+                           int w, int kernel, int ksize, double prior, int exclude_center,
+                           void *stream)
+{
+    VA_REQUIRE(src && mean_out, "va_image_statistics_u8: NULL argument");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0 && ksize >= 0, "va_image_statistics_u8: bad shape");
+    VA_REQUIRE(kernel == 0 || kernel == 1, "va_image_statistics_u8: kernel must be 0 (box) or 1 (ellipse)");
+    RowSpans se;
+    int rc = make_row_spans(kernel == 0 ? VA_SHAPE_RECT : VA_SHAPE_ELLIPSE, 2 * ksize + 1, &se);
+    if (rc)
+        return rc;
+    return launch_image_statistics(src, mean_out, var_out, n, h, w, se, prior, exclude_center,
+                                   as_stream(stream));
+}
+
 // ------------------------------------------------------------------------------ contour
 size_t va_contour_workspace_bytes(int n, int h, int w)
 {

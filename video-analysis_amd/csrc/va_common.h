@@ -135,6 +135,15 @@ int launch_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int o
 int launch_morph_bits(const uint32_t *src, uint32_t *dst, int n, int h, int w, int op,
                       const RowSpans &se, hipStream_t st);
 
+// small stencils (va_stencil.hip)
+int launch_detect_peaks(const uint8_t *src, uint8_t *dst, int n, int h, int w, int include_plateaus,
+                        hipStream_t st);
+int launch_thinning_step(const uint8_t *img, uint8_t *eroded, uint8_t *skel, int n, int h, int w,
+                         unsigned long long *nonzero, hipStream_t st);
+int launch_image_statistics(const uint8_t *src, double *mean_out, double *var_out, int n, int h,
+                            int w, const RowSpans &se, double prior, int exclude_center,
+                            hipStream_t st);
+
 // the whole op sequence in one LDS-resident kernel; labels_init != nullptr also plants the
 // labelling forest (then pass forest_ready = true to launch_ccl)
 bool morph_fused_supported(int w, const RowSpans *se, int count);

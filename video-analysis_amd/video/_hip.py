@@ -84,6 +84,9 @@ SIGNATURES = {
     "va_label_i32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "va_moments_i64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "va_largest_region": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "va_detect_peaks_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "va_mask_thinning_u8": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(_i), _vp]),
+    "va_image_statistics_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp]),
     "va_contour_workspace_bytes": (_sz, [_i, _i, _i]),
     "va_largest_contour": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "va_pipeline_create": (_i, [C.POINTER(va_config), C.POINTER(_vp)]),

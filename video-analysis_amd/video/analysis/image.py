@@ -107,3 +107,36 @@ class regionprops(object):
     @property
     def minor_axis_length(self):
         return 4 * math.sqrt(self.inertia_tensor_eigvals[1])
+
+
+def detect_peaks(img, include_plateaus=True):
+    """boolean mask of the pixels that are maximal in their 8-neighbourhood; with plateaus the
+    eroded zero-background is removed (reference :267-306)"""
+    from .. import ops
+    return ops.detect_peaks(img, include_plateaus)
+
+
+def mask_thinning(img, method="auto"):
+    """skeleton of a mask.  Only the reference's `python` method (iterated 3x3-cross
+    erosion/dilation, :243-258) exists on the GPU; 'guo-hall' needs the external `thinning`
+    module in the reference as well and is not provided."""
+    if method == "guo-hall":
+        raise ImportError("Using the `guo-hall` method for thinning requires the `thinning` "
+                          "module, which is not part of the GPU path.")
+    if method not in ("auto", "python"):
+        raise ValueError("Unknown thinning method `%s`" % method)
+    from .. import ops
+    return ops.mask_thinning(img)[0]
+
+
+def get_image_statistics(img, kernel="box", ksize=5, ret_var=True, prior=None,
+                         exclude_center=False):
+    """mean and variance in a window around every point of an image (reference :131-201).
+    `prior` is subtracted before summing (default: the image mean)."""
+    from .. import ops
+    img = np.asarray(img)
+    if prior is None:
+        prior = img.mean()
+    if kernel not in ("box", "ellipse", "circle"):
+        raise ValueError("Unknown filter kernel `%s`" % kernel)
+    return ops.image_statistics(img, kernel, int(ksize), prior, exclude_center, ret_var)

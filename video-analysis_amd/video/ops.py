@@ -292,3 +292,53 @@ def largest_contour(mask, max_points=None):
     finally:
         for b in bufs:
             b.free()
+
+
+def detect_peaks(img, include_plateaus=True):
+    """boolean mask of the local maxima (video/analysis/image.py:267-306), uint8 images"""
+    a = np.ascontiguousarray(img)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise TypeError("detect_peaks expects a 2-d uint8 image on the GPU path")
+    out = _pointwise_u8(_hip.lib().va_detect_peaks_u8, a, a.shape, 1, a.shape[0], a.shape[1],
+                        1 if include_plateaus else 0, None)
+    return out.astype(bool)
+
+
+def mask_thinning(img):
+    """skeleton by iterated 3x3-cross erosion/dilation (python method of mask_thinning,
+    video/analysis/image.py:243-258); returns (skeleton uint8, iterations)"""
+    a = np.ascontiguousarray(img, np.uint8)
+    if a.ndim != 2:
+        raise ValueError("mask must be 2-d")
+    h, w = a.shape
+    cur, tmp, skel = DeviceBuffer.from_array(a), DeviceBuffer(a.size), DeviceBuffer(a.size)
+    it = C.c_int()
+    try:
+        check(_hip.lib().va_mask_thinning_u8(cur.ptr, tmp.ptr, skel.ptr, h, w, C.byref(it), None))
+        return skel.download(a.shape, np.uint8), it.value
+    finally:
+        for b in (cur, tmp, skel):
+            b.free()
+
+
+def image_statistics(img, kernel="box", ksize=5, prior=0.0, exclude_center=False, ret_var=True):
+    """local mean (and variance) in a window around every pixel
+    (get_image_statistics, video/analysis/image.py:131-201), uint8 images"""
+    a = np.ascontiguousarray(img)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise TypeError("image_statistics expects a 2-d uint8 image on the GPU path")
+    h, w = a.shape
+    src = DeviceBuffer.from_array(a)
+    dm = DeviceBuffer(a.size * 8)
+    dv = DeviceBuffer(a.size * 8) if ret_var else None
+    try:
+        check(_hip.lib().va_image_statistics_u8(src.ptr, dm.ptr, dv.ptr if dv else None, 1, h, w,
+                                                {"box": 0, "ellipse": 1, "circle": 1}[kernel],
+                                                int(ksize), float(prior), 1 if exclude_center else 0,
+                                                None))
+        mean = dm.download(a.shape, np.float64)
+        return (mean, dv.download(a.shape, np.float64)) if ret_var else mean
+    finally:
+        for b in (src, dm, dv):
+            if b:
+                b.free()
