@@ -73,6 +73,17 @@ int va_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream
 int va_memset(void *dst_dev, int value, size_t bytes, void *stream);
 int va_stream_sync(void *stream);
 
+/* streams and events, for hosts that overlap uploads, the chain and downloads (the role of the
+ * reference's reader process / VideoPreprocessor threads, video/io/parallel.py:345-488) */
+int va_stream_create(void **stream_out);
+int va_stream_destroy(void *stream);
+int va_event_create(void **event_out);
+int va_event_destroy(void *event);
+int va_event_record(void *event, void *stream);
+int va_stream_wait_event(void *stream, void *event);
+int va_event_sync(void *event);
+int va_event_elapsed_ms(void *start_event, void *stop_event, float *ms_out);
+
 /* ------------------------------------------------------------------ A1 Gaussian blur
  * replaces  cv2.GaussianBlur(frame.astype(np.uint8), (0, 0), sigma)
  *           FilterBlur._process_frame, video/filters.py:388-392

@@ -165,6 +165,59 @@ int va_stream_sync(void *stream)
     return VA_OK;
 }
 
+int va_stream_create(void **stream_out)
+{
+    VA_REQUIRE(stream_out, "va_stream_create: NULL argument");
+    hipStream_t s;
+    VA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = (void *)s;
+    return VA_OK;
+}
+int va_stream_destroy(void *stream)
+{
+    if (stream)
+        VA_HIP(hipStreamDestroy(as_stream(stream)));
+    return VA_OK;
+}
+int va_event_create(void **event_out)
+{
+    VA_REQUIRE(event_out, "va_event_create: NULL argument");
+    hipEvent_t e;
+    VA_HIP(hipEventCreate(&e));
+    *event_out = (void *)e;
+    return VA_OK;
+}
+int va_event_destroy(void *event)
+{
+    if (event)
+        VA_HIP(hipEventDestroy((hipEvent_t)event));
+    return VA_OK;
+}
+int va_event_record(void *event, void *stream)
+{
+    VA_REQUIRE(event, "va_event_record: NULL event");
+    VA_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+    return VA_OK;
+}
+int va_stream_wait_event(void *stream, void *event)
+{
+    VA_REQUIRE(event, "va_stream_wait_event: NULL event");
+    VA_HIP(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
+    return VA_OK;
+}
+int va_event_sync(void *event)
+{
+    VA_REQUIRE(event, "va_event_sync: NULL event");
+    VA_HIP(hipEventSynchronize((hipEvent_t)event));
+    return VA_OK;
+}
+int va_event_elapsed_ms(void *start_event, void *stop_event, float *ms_out)
+{
+    VA_REQUIRE(start_event && stop_event && ms_out, "va_event_elapsed_ms: NULL argument");
+    VA_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)start_event, (hipEvent_t)stop_event));
+    return VA_OK;
+}
+
 // ------------------------------------------------------------------------------ Gaussian
 int va_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps_out, int capacity)
 {

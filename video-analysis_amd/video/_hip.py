@@ -69,6 +69,14 @@ SIGNATURES = {
     "va_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
     "va_memset": (_i, [_vp, _i, _sz, _vp]),
     "va_stream_sync": (_i, [_vp]),
+    "va_stream_create": (_i, [C.POINTER(_vp)]),
+    "va_stream_destroy": (_i, [_vp]),
+    "va_event_create": (_i, [C.POINTER(_vp)]),
+    "va_event_destroy": (_i, [_vp]),
+    "va_event_record": (_i, [_vp, _vp]),
+    "va_stream_wait_event": (_i, [_vp, _vp]),
+    "va_event_sync": (_i, [_vp]),
+    "va_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "va_gaussian_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "va_gaussian_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "va_gauss_taps_q8": (_i, [_d, C.POINTER(_i), _vp, _i]),
