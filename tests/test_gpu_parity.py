@@ -80,6 +80,20 @@ def test_gaussian_f32(ops, oracle, golden):
     assert np.array_equal(ops.gaussian_blur(c, 4.0, color=True), oracle.gaussian_f32(c, 4.0))
 
 
+@pytest.mark.parametrize("shape,color,sigma", [((2, 37, 53), False, 2.0), ((1, 64, 100, 3), True, 9.0),
+                                                ((2, 20, 31, 3), True, 1.0), ((1, 5, 7), False, 9.0),
+                                                ((1, 130, 257), False, 4.0), ((1, 90, 410, 3), True, 5.0),
+                                                ((1, 33, 20, 3), True, 10.0), ((1, 40, 60), False, 12.0)])
+def test_gaussian_f32_fast_and_generic_paths(ops, oracle, shape, color, sigma):
+    rng = np.random.default_rng(int(sigma * 10) + shape[1])
+    f = (rng.random(shape, dtype=np.float32) * 2 - 0.5).astype(np.float32)
+    f.flat[::97] = 0.0
+    f.flat[5::211] = -0.0
+    ref = oracle.gaussian_f32(f, sigma) if not color else oracle.gaussian_f32(f, sigma)
+    got = ops.gaussian_blur(f, sigma, color=color)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (shape, sigma)   # bit pattern
+
+
 def test_gaussian_1080p_properties(ops, oracle):
     """full BASELINE size: parity on a crop-sized oracle sample + size-independent properties"""
     rng = np.random.default_rng(11)

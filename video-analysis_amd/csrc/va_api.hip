@@ -300,6 +300,8 @@ int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, do
     rc = get_scratch((size_t)n * h * w * c * sizeof(float), &scratch);
     if (rc)
         return rc;
+    if (gauss_f32_fast_supported(w, c, t))
+        return launch_gauss_f32_fast(src, dst, (float *)scratch, n, h, w, c, t, as_stream(stream));
     return launch_gauss_generic_f32(src, dst, (float *)scratch, n, h, w, c, t, as_stream(stream));
 }
 
@@ -643,7 +645,13 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
         }
     }
     snprintf(p->desc, sizeof(p->desc), "bg=%d gauss=%s(ksize=%d) thresh=%d morph=%d ccl=%d",
-             cfg->bg_mode, cfg->sigma > 0 ? (p->fused ? "fused-lds" : "generic") : "none",
+             cfg->bg_mode,
+             cfg->sigma > 0 ? (p->fused ? "fused-lds"
+                                        : (cfg->dtype == VA_F32 &&
+                                                   gauss_f32_fast_supported(cfg->width, cfg->channels, p->tf)
+                                               ? "f32-lds-row+ring-col"
+                                               : "generic"))
+                            : "none",
              cfg->sigma > 0 ? (cfg->dtype == VA_U8 ? p->tq.ksize : p->tf.ksize) : 0, cfg->thresh,
              cfg->morph_count, cfg->connectivity);
 #undef PIPE_TRY
@@ -756,6 +764,9 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
                 rc = launch_gauss_generic_u8((const uint8_t *)cur, (uint8_t *)dst,
                                              (uint16_t *)p->gscratch, n, c.height, c.width,
                                              c.channels, p->tq, st);
+            else if (gauss_f32_fast_supported(c.width, c.channels, p->tf))
+                rc = launch_gauss_f32_fast((const float *)cur, (float *)dst, (float *)p->gscratch, n,
+                                           c.height, c.width, c.channels, p->tf, st);
             else
                 rc = launch_gauss_generic_f32((const float *)cur, (float *)dst,
                                               (float *)p->gscratch, n, c.height, c.width,

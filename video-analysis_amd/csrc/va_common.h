@@ -97,6 +97,10 @@ int launch_gauss_generic_u8(const uint8_t *src, uint8_t *dst, uint16_t *scratch,
                             int w, int c, const TapsQ8 &taps, hipStream_t st);
 int launch_gauss_generic_f32(const float *src, float *dst, float *scratch, int n, int h, int w,
                              int c, const TapsF32 &taps, hipStream_t st);
+// fast float32 path: LDS-staged row pass + register-window column pass (1 or 3 channels)
+bool gauss_f32_fast_supported(int w, int c, const TapsF32 &taps);
+int launch_gauss_f32_fast(const float *src, float *dst, float *scratch, int n, int h, int w, int c,
+                          const TapsF32 &taps, hipStream_t st);
 // fused single-channel u8 Gaussian (LDS-staged, dot4/dot2), radius <= 31; output either the
 // blurred u8 frames (dst), and/or the thresholded bit mask (bits, blurred > thresh)
 bool gauss_fused_supported(int w, int h, const TapsQ8 &taps);
