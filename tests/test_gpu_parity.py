@@ -602,3 +602,24 @@ def test_filter_classes_match_fused_chain_and_oracle(oracle):
     td = list(FilterTimeDifference(VideoMemory(clip)))
     assert len(td) == 9
     assert all(np.array_equal(td[k], clip[k + 1].astype(np.int16) - clip[k]) for k in range(9))
+
+
+def test_rccl_gather_counts_single_rank():
+    """the C ABI's own RCCL path (va_comm_* / va_gather_counts), world size 1 on this box; the
+    multi-rank layout is covered on CPU in tests/test_sharding.py"""
+    import ctypes as C
+    from video import _hip
+    from video._hip import DeviceBuffer, check
+    L = _hip.lib()
+    uid = (C.c_uint8 * 128)()
+    check(L.va_comm_unique_id(uid))
+    comm = C.c_void_p()
+    check(L.va_comm_init(C.byref(comm), 1, 0, uid))
+    counts = np.arange(17, dtype=np.int32) * 3
+    send, recv = DeviceBuffer.from_array(counts), DeviceBuffer(counts.nbytes)
+    check(L.va_gather_counts(comm, send.ptr, recv.ptr, len(counts), None))
+    check(L.va_stream_sync(None))
+    assert np.array_equal(recv.download(counts.shape, np.int32), counts)
+    check(L.va_comm_destroy(comm))
+    send.free()
+    recv.free()
