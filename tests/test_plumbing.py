@@ -191,3 +191,19 @@ def test_gaussian_noise_source_is_repeatable():
     assert g.shape == (5, 8, 16) and g[2].dtype == np.uint8
     assert np.array_equal(g[2], g[2]) and not np.array_equal(g[1], g[2])
     assert len(list(g)) == 5
+
+
+def test_replicate_and_drop_frames_are_index_maps():
+    from video.filters import FilterDropFrames, FilterReplicate
+    v, data = _video(7)
+    r = FilterReplicate(v, 3)
+    assert len(r) == 21 and [int(f[0, 0]) for f in r] == [int(d[0, 0]) for d in data] * 3
+    assert np.array_equal(r[9], data[2]) and np.array_equal(r[-1], data[6])
+    with pytest.raises(IndexError):
+        r.get_frame(21)
+    d = FilterDropFrames(v, 2)
+    assert len(d) == 4 and d.fps == v.fps / 2
+    assert [int(f[0, 0]) for f in d] == [int(data[k, 0, 0]) for k in (0, 2, 4, 6)]
+    assert len(FilterDropFrames(v, 2.5)) == 3 and np.array_equal(FilterDropFrames(v, 2.5)[2], data[5])
+    with pytest.raises(ValueError):
+        FilterReplicate(v, 0)

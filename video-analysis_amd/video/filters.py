@@ -225,6 +225,66 @@ class FilterMorphology(VideoFilterBase):
         return super(FilterMorphology, self)._process_frame(frame)
 
 
+class _FrameIndexFilter(VideoFilterBase):
+    """filters that only re-map frame indices (no pixel work): frame k of this video is frame
+    `_source_index(k)` of the source"""
+
+    def _source_index(self, index):
+        raise NotImplementedError
+
+    def _check_index(self, index):
+        if index < 0:
+            index += self.frame_count
+        if not 0 <= index < self.frame_count:
+            raise IndexError("Cannot access frame %d." % index)
+        return index
+
+    def set_frame_pos(self, index):
+        self._frame_pos = self._check_index(index)
+
+    def get_frame_pos(self):
+        return self._frame_pos
+
+    def get_frame(self, index):
+        index = self._check_index(index)
+        self._frame_pos = index + 1
+        return self._process_frame(self._source.get_frame(self._source_index(index)))
+
+    def get_next_frame(self):
+        if self._frame_pos >= self.frame_count:
+            raise StopIteration
+        return self.get_frame(self._frame_pos)
+
+
+class FilterReplicate(_FrameIndexFilter):
+    """plays the source `count` times in a row (reference :396-430)"""
+
+    def __init__(self, source, count=1):
+        self.count = int(count)
+        if self.count < 1:
+            raise ValueError("count must be at least 1")
+        super(FilterReplicate, self).__init__(source, frame_count=source.frame_count * self.count)
+
+    def _source_index(self, index):
+        return index % self._source.frame_count
+
+
+class FilterDropFrames(_FrameIndexFilter):
+    """keeps every `compression`-th frame (fractional factors allowed) and lowers the frame rate
+    accordingly (reference :434-483)"""
+
+    def __init__(self, source, compression=1):
+        if compression < 1:
+            raise ValueError("compression must be at least 1")
+        self._compression = compression
+        super(FilterDropFrames, self).__init__(
+            source, frame_count=int((source.frame_count - 1) / compression) + 1,
+            fps=source.fps / compression)
+
+    def _source_index(self, index):
+        return int(index * self._compression)
+
+
 # ======================================================================================
 # filters with temporal state
 # ======================================================================================
