@@ -123,25 +123,6 @@ __device__ __forceinline__ RowCtx row_ctx(int h, size_t total_rows)
     return c;
 }
 
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o, kWave);
-    return v;
-}
-
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        int t = __shfl_up(v, o, kWave);
-        if (lane >= o)
-            v += t;
-    }
-    return v;
-}
-
 // The sparse passes (init / link / flatten / rank) map a wave onto EIGHT consecutive rows:
 // lane = (row = lane & 7, word group = lane >> 3), each lane walks a contiguous span of the
 // row's words.  Compared with one row per wave this cuts the number of waves 8x and, more
