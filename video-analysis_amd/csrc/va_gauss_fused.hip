@@ -4,16 +4,16 @@
 //          FilterBlur._process_frame, video/filters.py:388-392
 // and, in the pipeline, the BUILD-DEFINED FilterThreshold that follows it.
 //
-// One workgroup owns a vertical strip of TW columns of one frame and MARCHES DOWN it, eight
+// One workgroup owns a vertical strip of TW columns of one frame and MARCHES DOWN it, sixteen
 // rows per step, so every input byte is read from HBM once (plus a 16-column halo) and nothing
 // but the final output is written:
 //
-//   global --(16 B/lane, prefetched one step ahead)--> s_in  : 8 staged input rows (u8)
+//   global --(16 B/lane, prefetched one step ahead)--> s_in  : 16 staged input rows (u8)
 //   row pass : v_dot4_u32_u8 over 36-byte windows of s_in with byte-shifted copies of the q8.8
 //              taps (all taps <= 255, so four taps x four pixels are one instruction)
 //              -> u16 results, two vertically adjacent rows packed per dword -> s_t ring
-//   col pass : every thread owns one column, keeps RP+4 packed row pairs in registers and
-//              produces 8 output rows with v_dot2_u32_u16 (two rows x two taps per instruction)
+//   col pass : every thread owns one column, keeps RP+8 packed row pairs in registers and
+//              produces 16 output rows with v_dot2_u32_u16 (two rows x two taps per instruction)
 //   output   : u8 bytes, and/or (blur > thresh) as a bit mask via wave ballots (8 B per wave-row)
 //
 // Arithmetic is exactly the oracle's: row sum u16 (<= 255*256), column sum u32,
@@ -51,7 +51,7 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 constexpr int kHalo = 16;   // staged columns left and right of the strip (>= padded radius)
-constexpr int kRows = 8;    // rows per step
+constexpr int kRowsPerStep = 16;   // 16 vs 8 rows per step: -1.5 % time (fixed costs amortised)
 
 struct FusedWeights {
     uint32_t wrow[4][9];  // byte weights for output o = 0..3 over the thread's 36-byte window
@@ -59,7 +59,7 @@ struct FusedWeights {
     uint32_t wo[17];      // (tap[2j-1], tap[2j]) pairs for odd output rows
 };
 
-template <int TW, int RP, bool HAS_DST, bool HAS_BITS>
+template <int TW, int RP, int ROWS, bool HAS_DST, bool HAS_BITS>
 __global__ void __launch_bounds__(TW)
 gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                    uint32_t *__restrict__ bits, int thresh, int h, int w, int w32, int nstrips,
@@ -67,38 +67,40 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
 {
     constexpr int IW = TW + 2 * kHalo;       // staged bytes per input row
     constexpr int IWD = IW / 4;
-    constexpr int NP = kRows / 2 + RP;       // packed row pairs the column pass reads
-    constexpr int LAG = (2 * RP + 7) / 8;    // steps between producing and consuming rows
-    constexpr int RING = NP + 4;
+    constexpr int PPS = ROWS / 2;            // packed pair-rows produced per step
+    constexpr int NP = PPS + RP;             // pair-rows the column pass reads
+    constexpr int LAG = (PPS - 1 + RP) / PPS;   // steps between producing and consuming rows
+    constexpr int RING = PPS * (LAG + 2);    // the next step's writes never touch this step's reads
     constexpr int VPR = IW / 16;             // 16-byte vectors per staged row
-    constexpr int NV = VPR * kRows;
+    constexpr int NV = VPR * ROWS;           // vectors staged per step
+    constexpr int VPT = (NV + TW - 1) / TW;  // ... per thread
     constexpr int UPR = TW / 4;              // row-pass units (4 pixels x 2 rows) per pair-row
-    static_assert(NV <= TW, "one prefetch vector per thread");
-    static_assert(RP <= 16 && (TW % 64) == 0, "unsupported geometry");
+    constexpr int UPT = PPS * UPR / TW;      // units per thread and step
+    static_assert(PPS * UPR % TW == 0, "row-pass units must divide evenly");
+    static_assert(RP <= 16 && (TW % 64) == 0 && NP <= PPS * (LAG + 1), "unsupported geometry");
+    static_assert(ROWS == 8 || ROWS == 16, "ballot packing below handles 8 or 16 rows");
 
-    __shared__ __attribute__((aligned(16))) uint32_t s_in[2][kRows][IWD];
+    __shared__ __attribute__((aligned(16))) uint32_t s_in[2][ROWS][IWD];
     __shared__ __attribute__((aligned(16))) uint32_t s_t[RING][TW];
 
     const int tid = threadIdx.x;
     const int strip = blockIdx.x % nstrips, f = blockIdx.x / nstrips;
     const int X0 = strip * TW;
     const uint8_t *img = src + (size_t)f * h * w;
-    const int vrow = tid / VPR, vcol = tid % VPR;
-    // This thread stages 16 columns [gx0, gx0+16) of one row per step.  Frame rows are 16-byte
-    // aligned and w % 16 == 0, so a vector lies entirely inside the frame or entirely outside.
-    // Outside vectors exist only next to the left/right frame border; they are the mirror
-    // image (BORDER_REFLECT_101) of in-frame columns and are assembled in registers from two
-    // aligned loads:   left : t[i] = col(16 - i)      right: t[i] = col(w - 2 - i)
-    const int gx0 = X0 - kHalo + vcol * 16;
-    const int kind = gx0 >= 0 && gx0 + 16 <= w ? 0 : (gx0 == -16 ? 1 : (gx0 == w ? 2 : 3));
-
+    // A staged vector = 16 columns [gx0, gx0+16) of one row.  Frame rows are 16-byte aligned and
+    // w % 16 == 0, so a vector lies entirely inside the frame or entirely outside.  Outside
+    // vectors exist only next to the left/right frame border; they are the mirror image
+    // (BORDER_REFLECT_101) of in-frame columns and are assembled in registers from two aligned
+    // loads:   left : t[i] = col(16 - i)      right: t[i] = col(w - 2 - i)
     auto ld16 = [&](const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); };
-    auto fetch = [&](int s) -> uint4 {
-        const int yy = reflect101(kRows * s + vrow - RP, h);
+    auto fetch = [&](int s, int v) -> uint4 {
+        const int vrow = v / VPR, vcol = v % VPR;
+        const int gx0 = X0 - kHalo + vcol * 16;
+        const int yy = reflect101(ROWS * s + vrow - RP, h);
         const uint8_t *rowp = img + (size_t)yy * w;
-        if (kind == 0)
+        if (gx0 >= 0 && gx0 + 16 <= w)
             return ld16(rowp + gx0);
-        if (kind == 1) {
+        if (gx0 == -16) {
             const uint4 A = ld16(rowp), B = ld16(rowp + 16);
             const uint32_t r0 = __builtin_bswap32(A.w), r1 = __builtin_bswap32(A.z),
                            r2 = __builtin_bswap32(A.y), r3 = __builtin_bswap32(A.x);
@@ -106,7 +108,7 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                               __builtin_amdgcn_alignbyte(r2, r1, 3),
                               __builtin_amdgcn_alignbyte(r3, r2, 3));
         }
-        if (kind == 2) {
+        if (gx0 == w) {
             const uint4 C = ld16(rowp + w - 32), D = ld16(rowp + w - 16);
             const uint32_t r0 = __builtin_bswap32(D.w), r1 = __builtin_bswap32(D.z),
                            r2 = __builtin_bswap32(D.y), r3 = __builtin_bswap32(D.x);
@@ -117,13 +119,17 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
         }
         return make_uint4(0, 0, 0, 0);   // columns whose results are never stored
     };
+    auto stage = [&](int buf, int v, const uint4 &val) {
+        *reinterpret_cast<uint4 *>(&s_in[buf][v / VPR][(v % VPR) * 4]) = val;
+    };
 
-    if (tid < NV)
-        *reinterpret_cast<uint4 *>(&s_in[0][vrow][vcol * 4]) = fetch(0);
+#pragma unroll
+    for (int i = 0; i < VPT; i++)
+        if (tid + i * TW < NV)
+            stage(0, tid + i * TW, fetch(0, tid + i * TW));
     __syncthreads();
 
-    const int nsteps = (h + kRows - 1) / kRows + LAG;
-    const int pr = tid / UPR, xq = tid % UPR;   // this thread's row-pass unit
+    const int nsteps = (h + ROWS - 1) / ROWS + LAG;
     const int x = X0 + tid;                     // this thread's column in the column pass
     const int wave = tid >> 6, lane = tid & 63;
 
@@ -140,13 +146,19 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     for (int s = 0; s < nsteps; s++) {
         const int buf = s & 1;
         const bool more = s + 1 < nsteps;
-        uint4 pre = make_uint4(0, 0, 0, 0);
-        const bool have_pre = more && tid < NV;
-        if (have_pre)
-            pre = fetch(s + 1);
+        uint4 pre[VPT];
+#pragma unroll
+        for (int i = 0; i < VPT; i++) {
+            pre[i] = make_uint4(0, 0, 0, 0);
+            if (more && tid + i * TW < NV)
+                pre[i] = fetch(s + 1, tid + i * TW);
+        }
 
-        // ---- row pass: virtual rows 8s+2pr and 8s+2pr+1, output columns 4xq..4xq+3
-        {
+        // ---- row pass: unit u = (pair-row pr, 4 columns xq): virtual rows ROWS*s + 2pr, +1
+#pragma unroll
+        for (int ui = 0; ui < UPT; ui++) {
+            const int u = tid + ui * TW;
+            const int pr = u / UPR, xq = u % UPR;
             const uint32_t *r0 = &s_in[buf][2 * pr][xq];
             const uint32_t *r1 = &s_in[buf][2 * pr + 1][xq];
             uint32_t d0[9], d1[9];
@@ -172,43 +184,52 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
 #pragma unroll
             for (int o = 0; o < 4; o++)
                 o4[o] = a0[o] | (a1[o] << 16);   // both <= 255*256
-            const int slot = (4 * s + pr) % RING;
+            const int slot = (PPS * s + pr) % RING;
             *reinterpret_cast<uint4 *>(&s_t[slot][4 * xq]) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
         }
 
         // ---- stage the next step's input rows into the other buffer
-        if (have_pre)
-            *reinterpret_cast<uint4 *>(&s_in[buf ^ 1][vrow][vcol * 4]) = pre;
+#pragma unroll
+        for (int i = 0; i < VPT; i++)
+            if (more && tid + i * TW < NV)
+                stage(buf ^ 1, tid + i * TW, pre[i]);
         __syncthreads();
 
-        // ---- column pass: output rows 8g..8g+7 of column x
+        // ---- column pass: output rows ROWS*g .. ROWS*g + ROWS-1 of column x
         const int g = s - LAG;
-        if (g >= 0 && kRows * g < h) {
+        if (g >= 0 && ROWS * g < h) {
             uint32_t pd[NP];
-            int slot = (4 * g) % RING;
+            int slot = (PPS * g) % RING;
 #pragma unroll
             for (int j = 0; j < NP; j++) {
                 pd[j] = s_t[slot][tid];
                 slot = slot + 1 == RING ? 0 : slot + 1;
             }
-            uint32_t acc[kRows];
+            uint32_t acc[ROWS];
 #pragma unroll
-            for (int i = 0; i < kRows; i++)
+            for (int i = 0; i < ROWS; i++)
                 acc[i] = 0;
 #pragma unroll
-            for (int j = 0; j <= RP; j++) {      // taps outermost: 8 independent dot2 chains
+            for (int j = 0; j <= RP; j++) {      // taps outermost: ROWS independent dot2 chains
 #pragma unroll
-                for (int i = 0; i < kRows; i++)
+                for (int i = 0; i < ROWS; i++)
                     acc[i] = udot2(pd[i / 2 + j], (i & 1) ? wo[j] : we[j], acc[i]);
                 // pin the interleaved order (the scheduler would otherwise re-serialise the chains)
-                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]),
-                                  "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
+                if (ROWS == 8)
+                    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]),
+                                      "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
+                else
+                    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]),
+                                      "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                                      "+v"(acc[8 % ROWS]), "+v"(acc[9 % ROWS]), "+v"(acc[10 % ROWS]),
+                                      "+v"(acc[11 % ROWS]), "+v"(acc[12 % ROWS]), "+v"(acc[13 % ROWS]),
+                                      "+v"(acc[14 % ROWS]), "+v"(acc[15 % ROWS]));
             }
-            const int y0 = kRows * g;
+            const int y0 = ROWS * g;
             const bool xin = x < w;
-            uint32_t myword = 0;                 // lane l < 16 stores row l>>1, half l&1
+            uint32_t myword = 0;                 // lane l < 2*ROWS stores row l>>1, half l&1
 #pragma unroll
-            for (int i = 0; i < kRows; i++) {
+            for (int i = 0; i < ROWS; i++) {
                 const uint32_t v = (acc[i] + 32768u) >> 16;
                 if (HAS_DST && xin && y0 + i < h)
                     dst[((size_t)f * h + y0 + i) * w + x] = (uint8_t)v;
@@ -221,7 +242,7 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
             if (HAS_BITS) {
                 const int wi = (X0 >> 5) + wave * 2 + (lane & 1);
                 const int yy = y0 + (lane >> 1);
-                if (lane < 2 * kRows && yy < h && wi < w32)
+                if (lane < 2 * ROWS && yy < h && wi < w32)
                     bits[((size_t)f * h + yy) * w32 + wi] = myword;
             }
         }
@@ -280,7 +301,7 @@ int launch_tw(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int 
     const int w32 = words_per_row(w);
     dim3 grid((unsigned)(nstrips * n));
 #define VA_GF_LAUNCH(RPV, D, B)                                                                  \
-    gauss_fused_kernel<TW, RPV, D, B><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt)
+    gauss_fused_kernel<TW, RPV, kRowsPerStep, D, B><<<grid, TW, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, wt)
 #define VA_GF_RP(RPV)                                      \
     do {                                                   \
         if (dst && bits)                                   \
