@@ -62,6 +62,7 @@ struct va_pipeline {
     void *bg_state;
     size_t bg_bytes;
     int64_t n_seen;
+    double *bg_recip;  // per-frame reciprocals of the running mean's divisor
     void *diff;        // background-subtracted frames (cfg.dtype)
     void *blur;        // blurred frames when the caller does not ask for them (generic path)
     void *gscratch;    // generic Gaussian scratch (u16 / f32)
@@ -309,7 +310,16 @@ int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, do
 int va_bg_update(int mode, int dtype, const void *frames, void *diff_out, void *state,
                  int64_t n_seen, double rate, int n, size_t px, void *stream)
 {
-    return launch_bg(mode, dtype, frames, diff_out, state, n_seen, rate, n, px, as_stream(stream));
+    double *recip = nullptr;
+    if (mode == VA_BG_MEAN && dtype == VA_U8 && n > 0) {
+        void *scratch;
+        int rc = get_scratch(bg_scratch_bytes(n), &scratch);
+        if (rc)
+            return rc;
+        recip = (double *)scratch;
+    }
+    return launch_bg(mode, dtype, frames, diff_out, state, n_seen, rate, n, px, as_stream(stream),
+                     recip);
 }
 int va_welford_u8(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
                   size_t px, void *stream)
@@ -521,7 +531,7 @@ int va_largest_contour(const uint8_t *mask, int n, int h, int w, int32_t *points
 // ------------------------------------------------------------------------------ pipeline
 static int pipeline_free(va_pipeline *p)
 {
-    void *ptrs[] = {p->bg_state, p->diff, p->blur, p->gscratch, p->bits[0], p->bits[1],
+    void *ptrs[] = {p->bg_state, p->bg_recip, p->diff, p->blur, p->gscratch, p->bits[0], p->bits[1],
                     p->ccl_ws,   p->labels_scratch, p->counts_scratch};
     for (void *q : ptrs)
         if (q)
@@ -629,6 +639,8 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
             return VA_ERR_HIP;
         }
         PIPE_MALLOC(p->diff, nb * p->px * esz);
+        if (cfg->bg_mode == VA_BG_MEAN)
+            PIPE_MALLOC(p->bg_recip, bg_scratch_bytes(cfg->max_batch));
     }
     if (cfg->sigma > 0 && !p->fused) {
         PIPE_MALLOC(p->gscratch, nb * p->px * (cfg->dtype == VA_U8 ? 2 : 4));
@@ -738,7 +750,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     // 1. background subtraction (temporal, in frame order)
     if (c.bg_mode != VA_BG_NONE) {
         rc = launch_bg(c.bg_mode, c.dtype, cur, p->diff, p->bg_state, p->n_seen, (double)c.bg_rate,
-                       n, p->px, st);
+                       n, p->px, st, p->bg_recip);
         if (rc)
             return rc;
         p->n_seen += n;

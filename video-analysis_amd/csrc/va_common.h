@@ -107,8 +107,11 @@ bool gauss_fused_supported(int w, int h, const TapsQ8 &taps);
 int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,
                           int h, int w, const TapsQ8 &taps, hipStream_t st);
 
+// recip_scratch: bg_scratch_bytes(n) bytes of device memory for the per-frame reciprocals of the
+// division-free running mean (nullptr: the plain-division kernel is used)
+size_t bg_scratch_bytes(int n);
 int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, int64_t n_seen,
-              double rate, int n, size_t px, hipStream_t st);
+              double rate, int n, size_t px, hipStream_t st, double *recip_scratch = nullptr);
 int launch_welford(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
                    size_t px, hipStream_t st);
 

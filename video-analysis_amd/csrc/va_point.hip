@@ -21,8 +21,10 @@ constexpr int kVec = 8;  // pixels per thread in the vector path (one 8-byte loa
 
 __device__ __forceinline__ uint8_t sat_u8_trunc(double d)
 {
-    d = d > 255.0 ? 255.0 : d;
-    return (uint8_t)(int)d;  // d >= 0: C truncation == trunc()
+    // d >= 0: C truncation == trunc(); saturate on the integer side (one v_min instead of an
+    // f64 compare + two selects).  Inputs beyond int range saturate in v_cvt_i32_f64 itself.
+    const int v = (int)d;
+    return (uint8_t)(v > 255 ? 255 : v);
 }
 
 // ---- cumulative mean, float64 state ------------------------------------------------------
@@ -88,9 +90,20 @@ __device__ __forceinline__ double div_by_uniform(double x, double d, double y)
     return fma(r, y, q);
 }
 
+// y[f] = RN(1 / (n_seen + f + 1)) for the frames of one batch (one division per frame, not one
+// per frame and thread)
+__global__ void __launch_bounds__(kBlock)
+bg_reciprocals_kernel(double *__restrict__ y, long long n_seen, int n)
+{
+    const int f = blockIdx.x * kBlock + threadIdx.x;
+    if (f < n)
+        y[f] = 1.0 / (double)(n_seen + f + 1);
+}
+
 __global__ void __launch_bounds__(kBlock)
 bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff,
-                       double *__restrict__ mean, long long n_seen, int n, size_t px)
+                       double *__restrict__ mean, const double *__restrict__ recip,
+                       long long n_seen, int n, size_t px)
 {
     constexpr int V = 8;
     size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * V;
@@ -111,7 +124,7 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
         uint8_t p[V], o[V];
         memcpy(p, &cur, 8);
         const double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
-        const double y = 1.0 / dn1;
+        const double y = recip[f];
 #pragma unroll
         for (int k = 0; k < V; k++) {
             const double fr = (double)p[k];
@@ -373,8 +386,10 @@ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_
 
 }  // namespace
 
+size_t bg_scratch_bytes(int n) { return sizeof(double) * (size_t)(n > 0 ? n : 1); }
+
 int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, int64_t n_seen,
-              double rate, int n, size_t px, hipStream_t st)
+              double rate, int n, size_t px, hipStream_t st, double *recip_scratch)
 {
     VA_REQUIRE(frames && state, "va_bg_update: frames/state must not be NULL");
     VA_REQUIRE(n >= 0 && px > 0, "va_bg_update: bad sizes n=%d px=%zu", n, px);
@@ -386,9 +401,11 @@ int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, 
         bool vec = (px % kVec == 0) && aligned(fr, 8) && (!df || aligned(df, 8));
         int grid = vec ? cdiv((long long)(px / kVec), kBlock) : cdiv((long long)px, kBlock);
         if (mode == VA_BG_MEAN) {
-            if (vec) {
-                bg_mean_u8_fast_kernel<<<grid, kBlock, 0, st>>>(fr, df, (double *)state, n_seen, n,
-                                                               px);
+            if (vec && recip_scratch) {
+                bg_reciprocals_kernel<<<cdiv(n, kBlock), kBlock, 0, st>>>(recip_scratch, n_seen, n);
+                VA_LAUNCH_CHECK("bg_reciprocals_kernel");
+                bg_mean_u8_fast_kernel<<<grid, kBlock, 0, st>>>(fr, df, (double *)state,
+                                                               recip_scratch, n_seen, n, px);
             } else if (vec)
                 bg_mean_u8_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, n_seen, n, px);
             else
