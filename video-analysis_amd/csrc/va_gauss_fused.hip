@@ -227,14 +227,15 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
             }
             const int y0 = ROWS * g;
             const bool xin = x < w;
+            const uint32_t acc_min = thresh < 0 ? 0u : (((uint32_t)thresh + 1u) << 16) - 32768u;
             uint32_t myword = 0;                 // lane l < 2*ROWS stores row l>>1, half l&1
 #pragma unroll
             for (int i = 0; i < ROWS; i++) {
-                const uint32_t v = (acc[i] + 32768u) >> 16;
                 if (HAS_DST && xin && y0 + i < h)
-                    dst[((size_t)f * h + y0 + i) * w + x] = (uint8_t)v;
+                    dst[((size_t)f * h + y0 + i) * w + x] = (uint8_t)((acc[i] + 32768u) >> 16);
                 if (HAS_BITS) {
-                    const unsigned long long b = __ballot(xin && (int)v > thresh);
+                    // ((acc + 2^15) >> 16) > thresh  <=>  acc >= ((thresh + 1) << 16) - 2^15
+                    const unsigned long long b = __ballot(xin && acc[i] >= acc_min);
                     const uint32_t half = (lane & 1) ? (uint32_t)(b >> 32) : (uint32_t)b;
                     myword = (lane >> 1) == i ? half : myword;
                 }
