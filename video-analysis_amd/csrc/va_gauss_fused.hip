@@ -234,10 +234,13 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                 if (HAS_DST && xin && y0 + i < h)
                     dst[((size_t)f * h + y0 + i) * w + x] = (uint8_t)((acc[i] + 32768u) >> 16);
                 if (HAS_BITS) {
-                    // ((acc + 2^15) >> 16) > thresh  <=>  acc >= ((thresh + 1) << 16) - 2^15
+                    // ((acc + 2^15) >> 16) > thresh  <=>  acc >= ((thresh + 1) << 16) - 2^15.
+                    // The compare result IS the 64-column bit row (an SGPR pair); v_writelane
+                    // drops its halves into lanes 2i and 2i+1 of the word the wave will store.
                     const unsigned long long b = __ballot(xin && acc[i] >= acc_min);
-                    const uint32_t half = (lane & 1) ? (uint32_t)(b >> 32) : (uint32_t)b;
-                    myword = (lane >> 1) == i ? half : myword;
+                    const uint32_t blo = (uint32_t)b, bhi = (uint32_t)(b >> 32);
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"(blo), "n"(2 * i));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"(bhi), "n"(2 * i + 1));
                 }
             }
             if (HAS_BITS) {
