@@ -228,6 +228,7 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
             const int y0 = ROWS * g;
             const bool xin = x < w;
             const uint32_t acc_min = thresh < 0 ? 0u : (((uint32_t)thresh + 1u) << 16) - 32768u;
+            const unsigned long long xmask = __ballot(xin);   // columns inside the frame
             uint32_t myword = 0;                 // lane l < 2*ROWS stores row l>>1, half l&1
 #pragma unroll
             for (int i = 0; i < ROWS; i++) {
@@ -237,7 +238,8 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                     // ((acc + 2^15) >> 16) > thresh  <=>  acc >= ((thresh + 1) << 16) - 2^15.
                     // The compare result IS the 64-column bit row (an SGPR pair); v_writelane
                     // drops its halves into lanes 2i and 2i+1 of the word the wave will store.
-                    const unsigned long long b = __ballot(xin && acc[i] >= acc_min);
+                    const unsigned long long b =
+                        __builtin_amdgcn_uicmp(acc[i], acc_min, 35 /* ICMP_UGE */) & xmask;
                     const uint32_t blo = (uint32_t)b, bhi = (uint32_t)(b >> 32);
                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"(blo), "n"(2 * i));
                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"(bhi), "n"(2 * i + 1));
