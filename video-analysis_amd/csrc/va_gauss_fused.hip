@@ -177,8 +177,10 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                     a0[o] = udot4(d0[d], wt.wrow[o][d], a0[o]);
                     a1[o] = udot4(d1[d], wt.wrow[o][d], a1[o]);
                 }
-                asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]),
-                                  "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));
+                // scheduling fence on all but the two accumulators written last: naming those
+                // too would make the compiler pad the dot -> use wait states with s_nops
+                asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]),
+                                  "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]));
             }
             uint32_t o4[4];
 #pragma unroll
@@ -217,13 +219,12 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                 // pin the interleaved order (the scheduler would otherwise re-serialise the chains)
                 if (ROWS == 8)
                     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]),
-                                      "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
+                                      "+v"(acc[4]), "+v"(acc[5]));
                 else
                     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]),
                                       "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
                                       "+v"(acc[8 % ROWS]), "+v"(acc[9 % ROWS]), "+v"(acc[10 % ROWS]),
-                                      "+v"(acc[11 % ROWS]), "+v"(acc[12 % ROWS]), "+v"(acc[13 % ROWS]),
-                                      "+v"(acc[14 % ROWS]), "+v"(acc[15 % ROWS]));
+                                      "+v"(acc[11 % ROWS]), "+v"(acc[12 % ROWS]), "+v"(acc[13 % ROWS]));
             }
             const int y0 = ROWS * g;
             const bool xin = x < w;
