@@ -474,6 +474,58 @@ def test_pipeline_1080p_full_chain(oracle):
     eng.close()
 
 
+def test_pipeline_full_baseline_batch_properties(oracle):
+    """BASELINE.json configs[2] at full size (256 x 1080p): the oracle cannot label 256 frames in
+    seconds, so the full batch is checked through size-independent properties plus exact oracle
+    comparisons on crops (background + blur are local up to the 15-pixel halo) and on two whole
+    frames chosen from the middle and the end of the batch."""
+    n, h, w = 256, 1080, 1920
+    rng = np.random.default_rng(3)
+    base = np.clip(rng.normal(100, 10, (h, w)), 0, 255)
+    clip = np.empty((n, h, w), np.uint8)
+    yy, xx = np.mgrid[:h, :w]
+    cx0, cy0 = rng.uniform(0, w, 24), rng.uniform(0, h, 24)
+    vx, vy = rng.uniform(-3, 3, 24), rng.uniform(-3, 3, 24)
+    rad = rng.uniform(8, 60, 24)
+    noise = rng.normal(0, 4, (8, h, w)).astype(np.float32)
+    for t in range(n):
+        f = base + noise[t % 8]
+        for k in range(24):
+            x0, y0, r = int(cx0[k] + vx[k] * t), int(cy0[k] + vy[k] * t), int(rad[k])
+            ya, yb, xa, xb = max(0, y0 - r), min(h, y0 + r + 1), max(0, x0 - r), min(w, x0 + r + 1)
+            if ya < yb and xa < xb:
+                sub = f[ya:yb, xa:xb]
+                sub[(xx[ya:yb, xa:xb] - x0) ** 2 + (yy[ya:yb, xa:xb] - y0) ** 2 <= r * r] += 60
+        clip[t] = np.clip(f, 0, 255).astype(np.uint8)
+    eng = _engine(size=(w, h), max_batch=n, background="mean", sigma=5.0, thresh=20,
+                  morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4)
+    out = eng.run(clip, want=("filtered", "mask", "labels", "counts"))
+    state, n_seen = eng.get_background()
+    eng.close()
+    labels, mask, counts = out["labels"], out["mask"], out["counts"]
+    # -- properties over the whole batch
+    assert n_seen == n and counts.min() >= 1
+    assert np.array_equal(labels != 0, mask != 0)                       # labels cover the mask
+    assert np.array_equal(labels.reshape(n, -1).max(1), counts)         # 1..L, L = count
+    first = np.array([np.flatnonzero(l.ravel())[0] for l in labels])    # SciPy order: label 1 first
+    assert all(labels[f].ravel()[first[f]] == 1 for f in range(n))
+    assert set(np.unique(mask)) <= {0, 255}
+    # -- exact: running mean and emitted differences on crops (pixel-local)
+    for (ya, xa) in ((0, 0), (500, 900), (1016, 1856)):
+        crop = np.ascontiguousarray(clip[:, ya:ya + 64, xa:xa + 64])
+        rd, rm = oracle.bg_mean_u8(crop)
+        assert np.array_equal(state[ya:ya + 64, xa:xa + 64], rm)
+        blur = oracle.gaussian_u8(rd, 5.0)          # exact away from the crop's own borders
+        assert np.array_equal(out["filtered"][:, ya + 15:ya + 49, xa + 15:xa + 49],
+                              blur[:, 15:49, 15:49])
+    # -- exact: two whole frames through the rest of the chain (threshold, close, label)
+    for f in (131, 255):
+        m = oracle.threshold_u8(out["filtered"][f], 20)
+        m = oracle.morph_u8(oracle.morph_u8(m, oracle.DILATE, oracle.RECT, 5), oracle.ERODE, oracle.RECT, 5)
+        rl, rc = oracle.label(m, 4)
+        assert np.array_equal(mask[f], m) and rc == counts[f] and np.array_equal(labels[f], rl)
+
+
 def test_pipeline_variants(oracle):
     clip = _blob_clip(5, 72, 100, seed=9)
     # no background model, 8-connectivity, open instead of close, maxval 1
