@@ -46,6 +46,7 @@ F32_WORKLOADS = {"cfg5_1080p_f32x3_sigma9": (1920, 1080, 3, 256, 9.0, 0.02)}
 STAGE_BYTES_PER_PX = {
     "bg": 1 + 1,                 # u8 frame in, u8 difference out (f64 state amortised per batch)
     "gauss_fused": 1 + 1 / 8,    # u8 in, thresholded bit mask out
+    "gauss_mfma": 1 + 1 / 8,     # the same contract on the matrix cores
     "gauss_generic": 1 + 1,      # u8 in, u8 out (the u16 scratch round trip is NOT compulsory)
     "threshold_pack": 1 + 1 / 8,
     "morph_fused": 2 / 8,        # bit mask in, bit mask out (+ forest seeds, sparse)

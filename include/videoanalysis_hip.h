@@ -259,10 +259,14 @@ int va_pipeline_stage_times(va_pipeline_t *p, int capacity, char *names, double 
 
 /* ------------------------------------------------------------------ test hooks
  * Same contracts as va_gaussian_u8 / va_morph_u8, but forcing one implementation so that the
- * parity tests can compare the generic two-pass Gaussian with the fused LDS kernel, and the
+ * parity tests can compare the generic two-pass Gaussian with the single-launch kernels, and the
  * bit-packed morphology used inside the pipeline with the u8 one (binary masks: != 0 -> 255). */
 int va_gaussian_u8_generic(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int c,
                            double sigma, void *stream);
+/* the LDS/VALU (dot4/dot2) single-launch kernel that va_gaussian_u8 falls back to when the tap
+ * set does not fit the matrix-core kernel (taps > 127); c must be 1 */
+int va_gaussian_u8_valu(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int c,
+                        double sigma, void *stream);
 int va_morph_bits_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int op,
                      int shape, int ksize, void *stream);
 

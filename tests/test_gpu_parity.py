@@ -59,6 +59,26 @@ def test_gaussian_u8_vs_oracle(ops, oracle, shape, sigma):
     assert np.array_equal(ops.gaussian_blur(im, sigma, implementation="generic"), ref)
 
 
+@pytest.mark.parametrize("shape,sigma", [((2, 64, 64), 5.0), ((1, 33, 80), 1.0), ((2, 100, 208), 5.3),
+                                         ((1, 32, 1936), 2.5), ((3, 77, 96), 0.7), ((1, 250, 336), 4.0),
+                                         ((1, 65, 112), 0.5), ((2, 129, 128), 3.3), ((1, 40, 64), 0.85)])
+def test_gaussian_u8_single_launch_kernels(ops, oracle, shape, sigma):
+    """shapes both single-launch kernels accept (w % 16 == 0, radius <= 16): the matrix-core
+    kernel (library's choice when every tap <= 127) and the dot4/dot2 kernel against the oracle"""
+    rng = np.random.default_rng(shape[2] + int(sigma * 10))
+    im = rng.integers(0, 256, shape, dtype=np.uint8)
+    im[0, :8, :] = 255                       # saturated borders: the largest row sums
+    im[0, -8:, :] = 0
+    im[-1, :, :24] = 255
+    im[-1, :, -24:] = 255
+    ref = oracle.gaussian_u8(im, sigma)
+    assert np.array_equal(ops.gaussian_blur(im, sigma), ref)
+    assert np.array_equal(ops.gaussian_blur(im, sigma, implementation="valu"), ref)
+    for v in (0, 255):                       # extremes of the int16 row sums / i8 offsets
+        c = np.full(shape, v, np.uint8)
+        assert np.array_equal(ops.gaussian_blur(c, sigma), c)
+
+
 def test_gaussian_u8_extremes_and_color(ops, oracle):
     for v in (0, 255, 77):
         c = np.full((2, 50, 70), v, np.uint8)

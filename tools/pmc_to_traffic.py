@@ -20,12 +20,12 @@ import re
 import sys
 
 STAGE_OF_KERNEL = {
-    "bg_mean_u8_fast_kernel": "bg", "bg_mean_u8_kernel": "bg", "gauss_fused_kernel": "gauss_fused",
+    "bg_mean_u8_fast_kernel": "bg", "bg_mean_u8_kernel": "bg", "gauss_fused_kernel": "gauss_fused", "gauss_mfma_kernel": "gauss_mfma",
     "morph_fused_kernel": "morph_fused", "morph_stream_kernel": "morph_fused", "ccl_init_kernel": "ccl_init", "ccl_link_kernel": "ccl_link",
     "ccl_flatten_kernel": "ccl_flatten", "ccl_rowscan_kernel": "ccl_rowscan",
     "ccl_rank_kernel": "ccl_rank", "ccl_paint_kernel": "ccl_paint",
 }
-WIDE_STREAM_READS = {"bg", "gauss_fused"}      # 8-16 B/lane coalesced loads: FETCH_SIZE x 2
+WIDE_STREAM_READS = {"bg", "gauss_fused", "gauss_mfma"}      # 8-16 B/lane coalesced loads: FETCH_SIZE x 2
 
 
 def per_kernel(path):

@@ -74,7 +74,8 @@ struct va_pipeline {
     TapsQ8 tq;
     TapsF32 tf;
     RowSpans se[VA_MAX_MORPH_OPS];
-    bool fused;
+    bool fused;   // single-launch blur(+threshold+bits): MFMA or LDS/VALU kernel
+    bool mfma;
     char desc[160];
     StageProfiler *prof;
 };
@@ -261,8 +262,13 @@ int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
     int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
     if (rc)
         return rc;
-    if (c == 1 && gauss_fused_supported(w, h, t) && reinterpret_cast<uintptr_t>(src) % 16 == 0)
-        return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
+    if (c == 1 && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(dst) % 4 == 0) {
+        if (gauss_mfma_supported(w, h, t))
+            return launch_gauss_mfma_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
+        if (gauss_fused_supported(w, h, t))
+            return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
+    }
     void *scratch;
     rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);
     if (rc)
@@ -285,6 +291,19 @@ int va_gaussian_u8_generic(const uint8_t *src, uint8_t *dst, int n, int h, int w
     if (rc)
         return rc;
     return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch, n, h, w, c, t, as_stream(stream));
+}
+
+// test hook: force the LDS/VALU (dot4/dot2) fused implementation
+int va_gaussian_u8_valu(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma,
+                        void *stream)
+{
+    VA_REQUIRE(src && dst && src != dst, "va_gaussian_u8_valu: bad pointers");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c == 1, "va_gaussian_u8_valu: bad shape");
+    TapsQ8 t;
+    int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
+    if (rc)
+        return rc;
+    return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
 }
 
 int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, double sigma,
@@ -616,7 +635,9 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
     if (cfg->sigma > 0) {
         if (cfg->dtype == VA_U8) {
             PIPE_TRY(gauss_taps_q8(cfg->sigma, &p->tq.ksize, p->tq.t, kMaxTaps));
-            p->fused = cfg->channels == 1 && gauss_fused_supported(cfg->width, cfg->height, p->tq);
+            p->mfma = cfg->channels == 1 && gauss_mfma_supported(cfg->width, cfg->height, p->tq);
+            p->fused = p->mfma ||
+                       (cfg->channels == 1 && gauss_fused_supported(cfg->width, cfg->height, p->tq));
         } else {
             PIPE_TRY(gauss_taps_f32(cfg->sigma, &p->tf.ksize, p->tf.t, kMaxTaps));
         }
@@ -658,7 +679,7 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
     }
     snprintf(p->desc, sizeof(p->desc), "bg=%d gauss=%s(ksize=%d) thresh=%d morph=%d ccl=%d",
              cfg->bg_mode,
-             cfg->sigma > 0 ? (p->fused ? "fused-lds"
+             cfg->sigma > 0 ? (p->fused ? (p->mfma ? "mfma-i8" : "fused-lds")
                                         : (cfg->dtype == VA_F32 &&
                                                    gauss_f32_fast_supported(cfg->width, cfg->channels, p->tf)
                                                ? "f32-lds-row+ring-col"
@@ -762,14 +783,14 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     bool have_bits = false;
     if (c.sigma > 0) {
         if (c.dtype == VA_U8 && p->fused) {
-            rc = launch_gauss_fused_u8((const uint8_t *)cur, (uint8_t *)filtered_out,
-                                       masks ? p->bits[0] : nullptr, c.thresh, n, c.height,
-                                       c.width, p->tq, st);
+            rc = (p->mfma ? launch_gauss_mfma_u8 : launch_gauss_fused_u8)(
+                (const uint8_t *)cur, (uint8_t *)filtered_out, masks ? p->bits[0] : nullptr,
+                c.thresh, n, c.height, c.width, p->tq, st);
             if (rc)
                 return rc;
             have_bits = masks;
             cur = filtered_out;  // may be NULL; not needed any more when have_bits
-            VA_MARK("gauss_fused");
+            VA_MARK(p->mfma ? "gauss_mfma" : "gauss_fused");
         } else {
             void *dst = filtered_out ? filtered_out : p->blur;
             if (c.dtype == VA_U8)

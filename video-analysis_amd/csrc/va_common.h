@@ -106,6 +106,11 @@ int launch_gauss_f32_fast(const float *src, float *dst, float *scratch, int n, i
 bool gauss_fused_supported(int w, int h, const TapsQ8 &taps);
 int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,
                           int h, int w, const TapsQ8 &taps, hipStream_t st);
+// the same contract on the matrix cores (Toeplitz products with v_mfma_i32_32x32x32_i8):
+// taps <= 127, radius <= 16; preferred whenever it applies
+bool gauss_mfma_supported(int w, int h, const TapsQ8 &taps);
+int launch_gauss_mfma_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,
+                         int h, int w, const TapsQ8 &taps, hipStream_t st);
 
 // recip_scratch: bg_scratch_bytes(n) bytes of device memory for the per-frame reciprocals of the
 // division-free running mean (nullptr: the plain-division kernel is used)

@@ -47,7 +47,8 @@ def gaussian_blur(frames, sigma, color=False, implementation=None):
     src = DeviceBuffer.from_array(arr)
     dst = DeviceBuffer(arr.nbytes)
     if arr.dtype == np.uint8:
-        fn = L.va_gaussian_u8_generic if implementation == "generic" else L.va_gaussian_u8
+        fn = {None: L.va_gaussian_u8, "generic": L.va_gaussian_u8_generic,
+              "valu": L.va_gaussian_u8_valu}[implementation]
     else:
         fn = L.va_gaussian_f32
     check(fn(src.ptr, dst.ptr, n, h, w, c, float(sigma), None))
