@@ -12,11 +12,13 @@
 // v_mfma_i32_32x32x32_i8: the matrix pipe does 1024 MAC/clk/SIMD against 57 for v_dot4.
 // All integer, so the result is bit-identical to the oracle's fixed-point definition.
 //
-// One WAVE owns a 32-column strip of one frame and marches down it 32 rows per step; waves do
-// not talk to each other (no barriers after start-up):
+// A workgroup of four waves owns a 128-column strip of one frame and marches down it 32 rows per
+// step; each wave computes one 32-column tile.  The input tile (32 rows x 160 columns with the
+// halo) is loaded by the whole workgroup, whole cache lines per row, so the L2->L1 traffic is
+// 3 lines per 128 useful bytes (per-wave 64-byte windows moved 6, and were L2-bandwidth bound):
 //
 //   global --16 B/lane, rows reflected (BORDER_REFLECT_101), prefetched one step ahead-->
-//   registers: x ^ 0x80 (u8 -> i8, x' = x - 128) --> per-wave LDS tile, 32 rows x 64 columns
+//   registers: x ^ 0x80 (u8 -> i8, x' = x - 128) --> LDS tile (double buffered, one barrier/step)
 //   row pass : A = pixels (lane = image row, 16 consecutive bytes of its LDS row),
 //              B = Toeplitz(taps) --> X[col on the lane][16 rows in registers] = sum w x'
 //              (|X| <= 2^15: exactly an int16)
@@ -45,9 +47,11 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef u4 u4_unaligned __attribute__((aligned(1)));
 
-constexpr int kWaves = 4;          // waves (strips) per workgroup
-constexpr int kLdsStride = 80;     // bytes per staged row: 64 + 16, stride/16 odd -> ds_read_b128
-                                   // of 32 rows is bank-conflict free
+constexpr int kWaves = 4;          // waves (32-column tiles) per workgroup
+constexpr int kTileCols = kWaves * 32;
+constexpr int kLdsStride = kTileCols + 32 + 16;   // staged row: strip + halo + pad; stride/16 odd
+                                                  // -> ds_read_b128 of 32 rows is conflict free
+static_assert((kLdsStride / 16) % 2 == 1, "LDS row stride must be an odd multiple of 16 bytes");
 constexpr int kTapTable = 128;     // zero-padded tap table, tap i at [48 + i]
 
 struct MfmaTaps {
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
     const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t *__restrict__ bits,
     int thresh, int h, int w, int w32, int nstrips, int blocks_per_frame, int nframes, MfmaTaps tp)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWaves][32 * kLdsStride];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[2][32 * kLdsStride];
     __shared__ int8_t s_taps[kTapTable];
 
     // ---- start-up: zero-padded tap table in LDS (the only workgroup-wide step) -------------
@@ -86,8 +90,9 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
     const int frame = (q / blocks_per_frame) * 8 + xcd;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int strip = (q % blocks_per_frame) * kWaves + wave;
-    if (frame >= nframes || strip >= nstrips)
+    if (frame >= nframes)                                // whole workgroup
         return;
+    const bool active = strip < nstrips;                 // waves right of the frame only load
 
     const int R = tp.ksize >> 1;
     const int nn = lane & 31, hh = lane >> 5;
@@ -124,77 +129,101 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
     const int k_dst = acc_min - 1 + 32768;   // (acc + 2^15) = k_dst - t
 
     const uint8_t *fsrc = src + (size_t)frame * h * w;
-    uint8_t *stage = s_stage[wave];
-    const int chunk = lane & 3, srow = lane >> 2;
-    const int xc = x0 - 16 + 16 * chunk;                 // first column of this lane's chunk
-    const bool border_strip = (x0 == 0) || (x0 + 48 > w);  // wave-uniform
-    const bool mirrored = xc < 0 || xc >= w;             // whole chunk outside (w % 16 == 0)
-    const int xs = xc < 0 ? -xc - 15 : (xc >= w ? 2 * w - 17 - xc : xc);
+    const int xb = (q % blocks_per_frame) * kTileCols;   // first column of the workgroup's strip
     const int ntiles = (h + 31) >> 5;                    // output tiles; row tiles 0..ntiles
 
+    // ---- cooperative loads: 32 rows x 10 chunks of 16 B.  load A: thread -> (row tid/8, chunk
+    //      tid%8): eight lanes per row read 128 contiguous bytes; load B: the last two chunks of
+    //      every row, issued by every wave alike (identical bytes land on identical LDS
+    //      addresses) so that all waves have the same number of loads in flight.
+    const int tid = threadIdx.x;
+    const int row_a = tid >> 3, ch_a = tid & 7;
+    const int row_b = lane >> 1, ch_b = 8 + (lane & 1);
+    auto chunk_src = [&](int ch, bool &mir) {            // source column of a chunk (w % 16 == 0)
+        const int xc = xb - 16 + 16 * ch;
+        mir = xc < 0 || xc >= w;
+        const int xs = xc < 0 ? -xc - 15 : (xc >= w ? 2 * w - 17 - xc : xc);
+        return min(max(xs, 0), w - 16);                  // far outside: never used, keep in range
+    };
+    bool mir_a, mir_b;
+    const int xs_a = chunk_src(ch_a, mir_a), xs_b = chunk_src(ch_b, mir_b);
+    const bool border_block = (xb == 0) || (xb + kTileCols + 16 > w);   // workgroup-uniform
+
+    auto row_of = [&](int t, int r) {                     // BORDER_REFLECT_101, then clamp
+        int y = 32 * t - 16 + r;
+        y = y < 0 ? -y : y;
+        y = y >= h ? 2 * (h - 1) - y : y;
+        return min(max(y, 0), h - 1);
+    };
     auto fetch = [&](int t, u4 &ga, u4 &gb) {
-#pragma unroll
-        for (int part = 0; part < 2; part++) {
-            int y = 32 * t - 16 + srow + 16 * part;
-            y = y < 0 ? -y : y;
-            y = y >= h ? 2 * (h - 1) - y : y;
-            y = min(max(y, 0), h - 1);
-            const uint8_t *p = fsrc + (size_t)y * w + xs;
-            u4 g;
-            if (!border_strip) {
-                g = *reinterpret_cast<const u4 *>(p);
-            } else {
-                g = *reinterpret_cast<const u4_unaligned *>(p);
-                const u4 r = {bswap32(g.w), bswap32(g.z), bswap32(g.y), bswap32(g.x)};
-                g = mirrored ? r : g;
-            }
-            (part ? gb : ga) = g;
+        const uint8_t *pa, *pb;
+        if (t >= 1 && 32 * t + 16 <= h) {                // tile inside the frame: add-only
+            const uint8_t *base = fsrc + (size_t)(32 * t - 16) * w;
+            pa = base + (size_t)row_a * w + xs_a;
+            pb = base + (size_t)row_b * w + xs_b;
+        } else {
+            pa = fsrc + (size_t)row_of(t, row_a) * w + xs_a;
+            pb = fsrc + (size_t)row_of(t, row_b) * w + xs_b;
         }
+        // straight-line loads (aligned except for mirrored border chunks)
+        ga = *reinterpret_cast<const u4_unaligned *>(pa);
+        if (wave == 0)
+            gb = *reinterpret_cast<const u4_unaligned *>(pb);
+    };
+    auto stage_write = [&](uint8_t *buf, u4 ga, u4 gb) {
+        if (border_block) {                               // uniform; VALU only
+            const u4 ra = {bswap32(ga.w), bswap32(ga.z), bswap32(ga.y), bswap32(ga.x)};
+            const u4 rb = {bswap32(gb.w), bswap32(gb.z), bswap32(gb.y), bswap32(gb.x)};
+            ga = mir_a ? ra : ga;
+            gb = mir_b ? rb : gb;
+        }
+        *reinterpret_cast<u4 *>(buf + row_a * kLdsStride + 16 * ch_a) = ga ^ 0x80808080u;
+        if (wave == 0)
+            *reinterpret_cast<u4 *>(buf + row_b * kLdsStride + 16 * ch_b) = gb ^ 0x80808080u;
     };
 
-    u4 ga, gb;
+    // sixteen registers that stay c_lo: the C operand of the low-byte chain
+    v16i c_init;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        c_init[i] = c_lo;
+    asm volatile("" : "+v"(c_init));
+
+    uint32_t *brow_ptr = bits + ((size_t)frame * h + nn) * w32 + strip;   // HAS_BITS
+    uint8_t *drow_ptr = dst + ((size_t)frame * h + nn) * w + x0 + 4 * hh; // HAS_DST
+    const int valid = min(32, w - x0);
+    const uint32_t colmask = valid < 32 ? (1u << valid) - 1u : ~0u;
+    const int frag_off = nn * kLdsStride + 32 * wave + 16 * hh;           // this lane's A bytes
+
+    u4 ga, gb = {};
     fetch(0, ga, gb);
+    stage_write(s_stage[0], ga, gb);
+    fetch(1, ga, gb);                                     // ntiles >= 1
+    __syncthreads();
     v4i prev_hi = {}, prev_lo = {};
+    v16i yh = {}, yl = {};
 
-    for (int t = 0; t <= ntiles; t++) {
-        // ---- stage row tile t (rows 32 t - 16 ...), prefetch the next one --------------------
-        *reinterpret_cast<u4 *>(stage + srow * kLdsStride + 16 * chunk) = ga ^ 0x80808080u;
-        *reinterpret_cast<u4 *>(stage + (srow + 16) * kLdsStride + 16 * chunk) = gb ^ 0x80808080u;
-        if (t < ntiles)
-            fetch(t + 1, ga, gb);
-        __builtin_amdgcn_wave_barrier();
-        const v4i a0 = *reinterpret_cast<const v4i *>(stage + nn * kLdsStride + 16 * hh);
-        const v4i a1 = *reinterpret_cast<const v4i *>(stage + nn * kLdsStride + 32 + 16 * hh);
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- row pass -------------------------------------------------------------------------
+    // Software pipeline, one barrier per step.  Step t:
+    //   row MFMAs of tile t  ||  epilogue of the column sums of output tile t-2 (issued last step)
+    //   stage tile t+1, prefetch tile t+2
+    //   repack tile t, issue the column MFMAs of output tile t-1 (consumed next step)
+    // so that neither MFMA result is waited for.  Steps 0, 1 and ntiles+1 run the same code on
+    // rows outside the frame: their stores are masked and their loads clamped.
+    for (int t = 0; t <= ntiles + 1; t++) {
+        const uint8_t *cur_buf = s_stage[t & 1];
+        uint8_t *next_buf = s_stage[(t + 1) & 1];
+        // ---- row pass of tile t (rows 32 t - 16 ...) ---------------------------------------------
+        const v4i a0 = *reinterpret_cast<const v4i *>(cur_buf + frag_off);
+        const v4i a1 = *reinterpret_cast<const v4i *>(cur_buf + frag_off + 32);
         v16i x = {};
         x = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, brow[0], x, 0, 0, 0);
         x = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, brow[1], x, 0, 0, 0);
 
-        // ---- accumulator -> two i8 operand fragments -----------------------------------------
-        v4i cur_hi, cur_lo;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)x[4 * g + 1], (uint32_t)x[4 * g], 0x05010400u);
-            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)x[4 * g + 3], (uint32_t)x[4 * g + 2], 0x05010400u);
-            cur_lo[g] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
-            cur_hi[g] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
-        }
-
-        if (t > 0) {
-            // ---- column pass for output rows 32 (t-1) ... -------------------------------------
-            v16i yh = {}, yl;
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                yl[i] = c_lo;
-            yh = __builtin_amdgcn_mfma_i32_32x32x32_i8(prev_hi, bcol[0], yh, 0, 0, 0);
-            yl = __builtin_amdgcn_mfma_i32_32x32x32_i8(prev_lo, bcol[0], yl, 0, 0, 0);
-            yh = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur_hi, bcol[1], yh, 0, 0, 0);
-            yl = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur_lo, bcol[1], yl, 0, 0, 0);
-
-            // lane = output row nn (+ half hh), register i = column (i&3) + 8 (i>>2) + 4 hh
-            const int y = 32 * (t - 1) + nn;
+        // ---- epilogue of output tile t-2: lane = output row nn (+ half hh), register i = column
+        //      (i&3) + 8 (i>>2) + 4 hh ---------------------------------------------------------------
+        {
+            const int y = 32 * (t - 2) + nn;
+            const bool row_ok = active && (unsigned)y < (unsigned)h;
             uint32_t p = 0;
             int tv[16];
 #pragma unroll
@@ -204,8 +233,8 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
                     p = __builtin_amdgcn_alignbit(p, (uint32_t)tv[i], 31);
             }
             if (HAS_DST) {
-                if (y < h) {
-                    uint8_t *drow = dst + ((size_t)frame * h + y) * w + x0 + 4 * hh;
+                if (row_ok) {
+                    uint8_t *drow = drow_ptr + (ptrdiff_t)(t - 2) * 32 * w;
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const uint32_t b0 = (uint32_t)(k_dst - tv[4 * g]) >> 16;
@@ -221,16 +250,36 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
             if (HAS_BITS) {
                 uint32_t wd = (p & 0xFu) | ((p & 0xF0u) << 4) | ((p & 0xF00u) << 8) | ((p & 0xF000u) << 12);
                 wd <<= 4 * hh;
-                wd |= (uint32_t)__shfl_xor((int)wd, 32, 64);
-                const int valid = min(32, w - x0);
-                if (valid < 32)
-                    wd &= (1u << valid) - 1u;
-                if (hh == 0 && y < h)
-                    bits[((size_t)frame * h + y) * w32 + strip] = wd;
+                // lanes 0..31 receive the word of lane + 32 (v_permlane32_swap, no LDS trip)
+                const auto sw = __builtin_amdgcn_permlane32_swap(wd, wd, false, false);
+                if (hh == 0 && row_ok)
+                    brow_ptr[(ptrdiff_t)(t - 2) * 32 * w32] = (wd | sw[1]) & colmask;
             }
         }
+
+        // ---- stage tile t+1 into the other buffer (nobody reads it before the barrier at the end
+        //      of this step; its previous readers passed the last barrier), prefetch tile t+2 ------
+        stage_write(next_buf, ga, gb);
+        fetch(min(t + 2, ntiles), ga, gb);
+
+        // ---- accumulator -> two i8 operand fragments -----------------------------------------
+        v4i cur_hi, cur_lo;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)x[4 * g + 1], (uint32_t)x[4 * g], 0x05010400u);
+            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)x[4 * g + 3], (uint32_t)x[4 * g + 2], 0x05010400u);
+            cur_lo[g] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+            cur_hi[g] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
+        }
+
+        // ---- column pass for output rows 32 (t-1) ..., consumed by the next step ----------------
+        yh = __builtin_amdgcn_mfma_i32_32x32x32_i8(prev_hi, bcol[0], v16i{}, 0, 0, 0);
+        yl = __builtin_amdgcn_mfma_i32_32x32x32_i8(prev_lo, bcol[0], c_init, 0, 0, 0);
+        yh = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur_hi, bcol[1], yh, 0, 0, 0);
+        yl = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur_lo, bcol[1], yl, 0, 0, 0);
         prev_hi = cur_hi;
         prev_lo = cur_lo;
+        __syncthreads();
     }
 }
 
@@ -269,7 +318,7 @@ int launch_gauss_mfma_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int t
         tp.sum += taps.t[i];
     }
     const int nstrips = cdiv(w, 32), w32 = words_per_row(w);
-    const int bpf = cdiv(nstrips, kWaves);
+    const int bpf = cdiv(w, kTileCols);
     dim3 grid((unsigned)(8 * cdiv(n, 8) * bpf));
     if (dst && bits)
         gauss_mfma_kernel<true, true><<<grid, kWaves * 64, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, bpf, n, tp);
