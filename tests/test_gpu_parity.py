@@ -3,6 +3,8 @@ and the committed golden vectors.  Bit-exact for every integer/byte/index result
 float64 running mean; the float32 Gaussian is bit-exact against the oracle's fmaf definition
 (tolerance vs real OpenCV per the north star: 1 ULP float32, unverifiable offline).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -240,7 +242,21 @@ def test_morphology_golden_and_oracle(ops, golden, oracle):
 
 
 # --------------------------------------------------------------------------- labelling
-def test_label_golden_scipy_vectors(ops, golden):
+@pytest.fixture(params=["frame-lds", "frame-large", "chip-wide"])
+def ccl_mode(request):
+    """the three labelling code paths of launch_ccl (va_ccl.hip), selected through the library's
+    test hooks: one workgroup per frame with the forest in LDS (default), the same kernel's
+    large-frame mode (forest in the label image; forced by a tiny LDS budget), and the chip-wide
+    multi-pass path that frames taller than the LDS row table take"""
+    env = {"frame-lds": {}, "frame-large": {"VA_CCL_LDS_RUNS": "7"},
+           "chip-wide": {"VA_CCL_LEGACY": "1"}}[request.param]
+    os.environ.update(env)
+    yield request.param
+    for k in env:
+        del os.environ[k]
+
+
+def test_label_golden_scipy_vectors(ops, golden, ccl_mode):
     for name in [str(n) for n in golden["mask_names"]]:
         m = golden["mask_" + name]
         for conn in (4, 8):
@@ -257,7 +273,7 @@ def test_label_golden_scipy_vectors(ops, golden):
                                                (31, 2100, 0.5, 5), (300, 65, 0.7, 6),
                                                (128, 4160, 0.59, 7), (1, 500, 0.5, 8),
                                                (500, 1, 0.5, 9)])
-def test_label_random_vs_oracle(ops, oracle, h, w, density, seed):
+def test_label_random_vs_oracle(ops, oracle, h, w, density, seed, ccl_mode):
     rng = np.random.default_rng(seed)
     m = (rng.random((3, h, w)) < density).astype(np.uint8)
     for conn in (4, 8):
@@ -267,7 +283,7 @@ def test_label_random_vs_oracle(ops, oracle, h, w, density, seed):
         assert np.array_equal(lab, rl), conn
 
 
-def test_label_adversarial(ops, oracle):
+def test_label_adversarial(ops, oracle, ccl_mode):
     cases = {}
     cases["empty"] = np.zeros((40, 70), np.uint8)
     cases["full"] = np.ones((40, 70), np.uint8)
@@ -343,7 +359,7 @@ def test_region_stats_and_moments(ops, oracle, golden):
         assert np.array_equal(st[f, :cnt[f], :14], oracle.region_stats(lab[f], int(cnt[f]))[:, :14])
 
 
-def test_largest_region_and_regionprops(ops, oracle, golden):
+def test_largest_region_and_regionprops(ops, oracle, golden, ccl_mode):
     from video.analysis import image, regions
     for name in [str(n) for n in golden["mask_names"]]:
         m = golden["mask_" + name]
@@ -370,7 +386,7 @@ def test_largest_region_and_regionprops(ops, oracle, golden):
     assert 0 <= rp.eccentricity <= 1 and rp.major_axis_length >= rp.minor_axis_length > 0
 
 
-def test_contour_of_largest_region(ops, oracle, golden):
+def test_contour_of_largest_region(ops, oracle, golden, ccl_mode):
     """A8 get_contour_from_largest_region: GPU (8-conn label roots + border following) vs the
     oracle's full Suzuki-Abe scanner, incl. nested components, ties and single pixels"""
     from video.analysis import regions

@@ -845,12 +845,14 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     }
     bool forest_ready = false;
     if (c.morph_count > 0 && morph_fused_supported(c.width, p->se, c.morph_count)) {
-        rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], labels, n, c.height, c.width, c.morph_op,
+        // the chip-wide labelling path wants its forest planted by the last morphology op
+        int32_t *plant = ccl_frame_kernel_used(c.height) ? nullptr : labels;
+        rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], plant, n, c.height, c.width, c.morph_op,
                                 p->se, c.morph_count, st);
         if (rc)
             return rc;
         b ^= 1;
-        forest_ready = labels != nullptr;
+        forest_ready = plant != nullptr;
         VA_MARK("morph_fused");
     } else {
         for (int i = 0; i < c.morph_count; i++) {

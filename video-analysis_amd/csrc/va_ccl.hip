@@ -157,6 +157,25 @@ __device__ __forceinline__ SpanCtx span_ctx(int h, int w32, size_t total_rows)
 }
 
 // ---- K1: every run's first pixel becomes a singleton tree ---------------------------------
+// (the *_span functions are the per-lane bodies: the chip-wide kernels below map lanes to rows
+// through blockIdx, the per-frame kernel's large-frame mode loops over its frame's rows)
+__device__ __forceinline__ void init_span(const uint32_t *row, int32_t *L, int y, int w, int w0,
+                                          int w1)
+{
+    uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
+    for (int wi = w0; wi < w1; wi++) {
+        const uint32_t m = row[wi];
+        uint32_t s = m & ~((m << 1) | prev);
+        prev = m >> 31;
+        while (s) {
+            int b = __ffs(s) - 1;
+            s &= s - 1;
+            int idx = y * w + (wi << 5) + b;
+            L[idx] = idx;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 ccl_init_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
                 int w32, size_t total_rows)
@@ -164,37 +183,18 @@ ccl_init_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
     const SpanCtx c = span_ctx(h, w32, total_rows);
     if (!c.valid)
         return;
-    const uint32_t *row = bits + c.row * w32;
-    int32_t *L = labels + (size_t)c.f * h * w;
-    uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
-    for (int wi = c.w0; wi < c.w1; wi++) {
-        const uint32_t m = row[wi];
-        uint32_t s = m & ~((m << 1) | prev);
-        prev = m >> 31;
-        while (s) {
-            int b = __ffs(s) - 1;
-            s &= s - 1;
-            int idx = c.y * w + (wi << 5) + b;
-            L[idx] = idx;
-        }
-    }
+    init_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1);
 }
 
 // ---- K2: link runs of row y with runs of row y-1 --------------------------------------------
 template <bool CONN8>
-__global__ void __launch_bounds__(kBlock)
-ccl_link_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
-                int w32, size_t total_rows)
+__device__ __forceinline__ void link_span(const uint32_t *row, int32_t *L, int y, int w, int w32,
+                                          int w0, int w1)
 {
-    const SpanCtx c = span_ctx(h, w32, total_rows);
-    if (!c.valid || c.y == 0)
-        return;
-    const uint32_t *row = bits + c.row * w32;
     const uint32_t *up = row - w32;
-    int32_t *L = labels + (size_t)c.f * h * w;
-    const int base = c.y * w, ubase = (c.y - 1) * w;
-    uint32_t mp = c.w0 > 0 ? row[c.w0 - 1] : 0u, upv = c.w0 > 0 ? up[c.w0 - 1] : 0u;
-    for (int wi = c.w0; wi < c.w1; wi++) {
+    const int base = y * w, ubase = (y - 1) * w;
+    uint32_t mp = w0 > 0 ? row[w0 - 1] : 0u, upv = w0 > 0 ? up[w0 - 1] : 0u;
+    for (int wi = w0; wi < w1; wi++) {
         const uint32_t m = row[wi], u = up[wi];
         // vertical contacts: one union per maximal run of (m & u)
         uint32_t v = m & u;
@@ -233,37 +233,72 @@ ccl_link_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
     }
 }
 
+template <bool CONN8>
+__global__ void __launch_bounds__(kBlock)
+ccl_link_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
+                int w32, size_t total_rows)
+{
+    const SpanCtx c = span_ctx(h, w32, total_rows);
+    if (!c.valid || c.y == 0)
+        return;
+    link_span<CONN8>(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, w32, c.w0, c.w1);
+}
+
 // ---- K3: flatten every run to its root, count roots per row ---------------------------------
+__device__ __forceinline__ int flatten_span(const uint32_t *row, int32_t *L, int y, int w, int w0,
+                                            int w1)
+{
+    int cnt = 0;
+    uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
+    for (int wi = w0; wi < w1; wi++) {
+        const uint32_t m = row[wi];
+        uint32_t s = m & ~((m << 1) | prev);
+        prev = m >> 31;
+        while (s) {
+            int b = __ffs(s) - 1;
+            s &= s - 1;
+            int idx = y * w + (wi << 5) + b;
+            int r = find_root_ro(L, idx);
+            if (r == idx)
+                cnt++;
+            else
+                st_forest(L + idx, r);
+        }
+    }
+    return cnt;
+}
+
+// sum over the 8 word groups of each row (lanes with equal lane & 7)
+__device__ __forceinline__ int row_sum(int v)
+{
+    v += __shfl_xor(v, 8, kWave);
+    v += __shfl_xor(v, 16, kWave);
+    v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+// exclusive prefix over the word groups of each row (lanes lane & 7, lane & 7 + 8, ...)
+__device__ __forceinline__ int row_prefix(int v, int lane)
+{
+    int incl = v;
+#pragma unroll
+    for (int o = 8; o < kWave; o <<= 1) {
+        int t = __shfl_up(incl, o, kWave);
+        if (lane >= o)
+            incl += t;
+    }
+    return incl - v;
+}
+
 __global__ void __launch_bounds__(kBlock)
 ccl_flatten_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
                    int32_t *__restrict__ row_cnt, int h, int w, int w32, size_t total_rows)
 {
     const SpanCtx c = span_ctx(h, w32, total_rows);
     int cnt = 0;
-    if (c.valid) {
-        const uint32_t *row = bits + c.row * w32;
-        int32_t *L = labels + (size_t)c.f * h * w;
-        uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
-        for (int wi = c.w0; wi < c.w1; wi++) {
-            const uint32_t m = row[wi];
-            uint32_t s = m & ~((m << 1) | prev);
-            prev = m >> 31;
-            while (s) {
-                int b = __ffs(s) - 1;
-                s &= s - 1;
-                int idx = c.y * w + (wi << 5) + b;
-                int r = find_root_ro(L, idx);
-                if (r == idx)
-                    cnt++;
-                else
-                    st_forest(L + idx, r);
-            }
-        }
-    }
-    // sum over the 8 word groups of each row (lanes with equal lane & 7)
-    cnt += __shfl_xor(cnt, 8, kWave);
-    cnt += __shfl_xor(cnt, 16, kWave);
-    cnt += __shfl_xor(cnt, 32, kWave);
+    if (c.valid)
+        cnt = flatten_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1);
+    cnt = row_sum(cnt);
     if (c.lane < kRowsPerWave && c.row < total_rows)
         row_cnt[c.row] = cnt;
 }
@@ -301,55 +336,379 @@ ccl_rowscan_kernel(const int32_t *__restrict__ row_cnt, int32_t *__restrict__ ro
 }
 
 // ---- K5: roots get their final label, stored negated ----------------------------------------
-__global__ void __launch_bounds__(kBlock)
-ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
-                const int32_t *__restrict__ row_off, int h, int w, int w32, size_t total_rows)
+// all lanes of the wave must call (shuffles); `valid` lanes own a row and a non-empty span
+__device__ __forceinline__ void rank_span(const uint32_t *row, int32_t *L, int y, int w, int w0,
+                                          int w1, int lane, bool valid, int row_offset)
 {
-    const SpanCtx c = span_ctx(h, w32, total_rows);
-    const uint32_t *row = bits + (c.row < total_rows ? c.row : 0) * w32;
-    int32_t *L = labels + (size_t)c.f * h * w;
     // pass 1: roots in this lane's span
     int nroots = 0;
-    if (c.valid) {
-        uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
-        for (int wi = c.w0; wi < c.w1; wi++) {
+    if (valid) {
+        uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
+        for (int wi = w0; wi < w1; wi++) {
             const uint32_t m = row[wi];
             uint32_t s = m & ~((m << 1) | prev);
             prev = m >> 31;
             while (s) {
                 int b = __ffs(s) - 1;
                 s &= s - 1;
-                int idx = c.y * w + (wi << 5) + b;
+                int idx = y * w + (wi << 5) + b;
                 nroots += L[idx] == idx;
             }
         }
     }
-    // exclusive prefix over the row's word groups (lanes lane&7, lane&7 + 8, ...)
-    int incl = nroots;
-#pragma unroll
-    for (int o = 8; o < kWave; o <<= 1) {
-        int t = __shfl_up(incl, o, kWave);
-        if (c.lane >= o)
-            incl += t;
-    }
-    if (!c.valid)
+    const int before = row_prefix(nroots, lane);
+    if (!valid)
         return;
-    int k = row_off[c.row] + incl - nroots;
+    int k = row_offset + before;
     // pass 2: number them (roots still hold L[idx] == idx: only this lane rewrites its span)
-    uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
-    for (int wi = c.w0; wi < c.w1; wi++) {
+    uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
+    for (int wi = w0; wi < w1; wi++) {
         const uint32_t m = row[wi];
         uint32_t s = m & ~((m << 1) | prev);
         prev = m >> 31;
         while (s) {
             int b = __ffs(s) - 1;
             s &= s - 1;
-            int idx = c.y * w + (wi << 5) + b;
+            int idx = y * w + (wi << 5) + b;
             if (L[idx] == idx)
                 L[idx] = -(++k);
         }
     }
 }
+
+__global__ void __launch_bounds__(kBlock)
+ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
+                const int32_t *__restrict__ row_off, int h, int w, int w32, size_t total_rows)
+{
+    const SpanCtx c = span_ctx(h, w32, total_rows);
+    const uint32_t *row = bits + (c.row < total_rows ? c.row : 0) * w32;
+    rank_span(row, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1, c.lane, c.valid,
+              c.valid ? row_off[c.row] : 0);
+}
+
+// ---- per-frame labelling: one workgroup owns one frame, forest in LDS ------------------------
+// The five chip-wide passes above cost ~0.28 ms per 256 x 1080p batch although they move
+// almost no data: every hop of a union-find walk is a dependent access to a sparse node in the
+// 2 GB label image.  A frame's forest is tiny (a 1080p frame has ~3 k runs), so one workgroup
+// per frame keeps it in LDS:
+//   * runs get COMPACT ids in raster order: id = (runs in earlier rows, from an exclusive scan
+//     of per-row run counts) + (run starts at or left of the pixel, by popcounts) - 1.  No
+//     backward search for a run's first pixel, no node in global memory;
+//   * unions are ds_min atomics towards the smaller id, so the root is again the component's
+//     first run in raster order and label = 1 + number of roots with a smaller id;
+//   * the only global traffic is the bit mask (L2-resident, read four times) and one sparse
+//     write per run: -(label) at the run's first pixel (bit 30 set for runs that are not their
+//     component's first), which is exactly what ccl_paint_kernel / the contour tracer consume.
+// Frames with more runs than the LDS table holds (noise, checkerboards) are labelled by the
+// same workgroup with the forest in the label image (the *_span bodies above): same result,
+// one CU per frame.
+constexpr int kFrameThreads = 1024;
+constexpr int kFrameWaves = kFrameThreads / kWave;                // 16
+constexpr int kFrameRowsPerIter = kFrameWaves * kRowsPerWave;     // 128 rows per sweep step
+constexpr int kLdsRuns = 32768;                                   // 128 KB of parents
+constexpr int kLdsRows = 4400;                                    // row table (8K-tall frames: legacy)
+constexpr int kNonRootBit = 1 << 30;
+
+__device__ __forceinline__ int lds_ld(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(int *p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int lds_find_root(int *P, int a)
+{
+    for (;;) {
+        const int p = lds_ld(P + a);
+        if (p == a)
+            return a;
+        const int gp = lds_ld(P + p);
+        if (gp == p)
+            return p;
+        lds_st(P + a, gp);   // path halving: any ancestor is a valid parent
+        a = gp;
+    }
+}
+__device__ __forceinline__ int lds_find_root_ro(const int *P, int a)
+{
+    for (;;) {
+        const int p = lds_ld(P + a);
+        if (p == a)
+            return a;
+        a = p;
+    }
+}
+__device__ __forceinline__ void lds_unite(int *P, int a, int b)
+{
+    for (;;) {
+        a = lds_find_root(P, a);
+        b = lds_find_root(P, b);
+        if (a == b)
+            return;
+        if (a > b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(P + b, a);   // a < b
+        if (old == b)
+            return;
+        b = old;
+    }
+}
+
+struct FrameSpan {
+    bool valid;   // this lane has a row of the frame and a non-empty word span
+    int lane, y, w0, w1;
+};
+__device__ __forceinline__ FrameSpan frame_span(int it, int h, int w32)
+{
+    FrameSpan c;
+    c.lane = threadIdx.x & (kWave - 1);
+    c.y = it * kFrameRowsPerIter + (int)(threadIdx.x >> 6) * kRowsPerWave + (c.lane & (kRowsPerWave - 1));
+    const int g = c.lane >> 3, G = (w32 + 7) >> 3;
+    c.w0 = g * G;
+    c.w1 = min(w32, c.w0 + G);
+    c.valid = c.y < h && c.w0 < c.w1;
+    return c;
+}
+
+// run starts in a span of a row
+__device__ __forceinline__ int count_starts(const uint32_t *row, int w0, int w1)
+{
+    int n = 0;
+    uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
+    for (int wi = w0; wi < w1; wi++) {
+        const uint32_t m = row[wi];
+        n += __popc(m & ~((m << 1) | prev));
+        prev = m >> 31;
+    }
+    return n;
+}
+
+// bits 0..b of a word
+__device__ __forceinline__ uint32_t upto(int b) { return (2u << b) - 1u; }
+
+// exclusive scan of one value per thread over the workgroup; *total (LDS) receives the sum
+__device__ __forceinline__ int block_exclusive_scan(int v, int *s_part, int *total)
+{
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(incl, o, kWave);
+        if (lane >= o)
+            incl += t;
+    }
+    if (lane == kWave - 1)
+        s_part[wv] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < kFrameWaves; i++) {
+        const int p = s_part[i];
+        before += i < wv ? p : 0;
+        all += p;
+    }
+    if (threadIdx.x == 0)
+        *total = all;
+    __syncthreads();
+    return before + incl - v;
+}
+
+template <bool CONN8>
+__global__ void __launch_bounds__(kFrameThreads)
+ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
+                 int32_t *__restrict__ counts, int h, int w, int w32, int lds_runs)
+{
+    __shared__ int s_parent[kLdsRuns];
+    __shared__ int s_rowbase[kLdsRows];
+    __shared__ int s_part[kFrameWaves];
+    __shared__ int s_total;
+
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t *fbits = bits + (size_t)f * h * w32;
+    int32_t *L = labels + (size_t)f * h * w;
+    const int sweeps = (h + kFrameRowsPerIter - 1) / kFrameRowsPerIter;
+    const int rows_per_thread = (h + kFrameThreads - 1) / kFrameThreads;
+    const int ty0 = min(h, tid * rows_per_thread), ty1 = min(h, ty0 + rows_per_thread);
+
+    // ---- 1. runs per row, exclusive scan -> first run id of every row -----------------------
+    for (int it = 0; it < sweeps; it++) {
+        const FrameSpan c = frame_span(it, h, w32);
+        int n = c.valid ? count_starts(fbits + (size_t)c.y * w32, c.w0, c.w1) : 0;
+        n = row_sum(n);
+        if (c.lane < kRowsPerWave && c.y < h)
+            s_rowbase[c.y] = n;
+    }
+    __syncthreads();
+    {
+        int sum = 0;
+        for (int y = ty0; y < ty1; y++)
+            sum += s_rowbase[y];
+        int run = block_exclusive_scan(sum, s_part, &s_total);
+        for (int y = ty0; y < ty1; y++) {
+            const int n = s_rowbase[y];
+            s_rowbase[y] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+    const int nruns = s_total;
+
+    if (nruns > lds_runs) {
+        // ---- large-frame mode: forest in the label image, same passes as the chip-wide path ---
+        for (int it = 0; it < sweeps; it++) {
+            const FrameSpan c = frame_span(it, h, w32);
+            if (c.valid)
+                init_span(fbits + (size_t)c.y * w32, L, c.y, w, c.w0, c.w1);
+        }
+        __syncthreads();
+        for (int it = 0; it < sweeps; it++) {
+            const FrameSpan c = frame_span(it, h, w32);
+            if (c.valid && c.y > 0)
+                link_span<CONN8>(fbits + (size_t)c.y * w32, L, c.y, w, w32, c.w0, c.w1);
+        }
+        __syncthreads();
+        for (int it = 0; it < sweeps; it++) {
+            const FrameSpan c = frame_span(it, h, w32);
+            int n = c.valid ? flatten_span(fbits + (size_t)c.y * w32, L, c.y, w, c.w0, c.w1) : 0;
+            n = row_sum(n);
+            if (c.lane < kRowsPerWave && c.y < h)
+                s_rowbase[c.y] = n;
+        }
+        __syncthreads();
+        {
+            int sum = 0;
+            for (int y = ty0; y < ty1; y++)
+                sum += s_rowbase[y];
+            int run = block_exclusive_scan(sum, s_part, &s_total);
+            for (int y = ty0; y < ty1; y++) {
+                const int n = s_rowbase[y];
+                s_rowbase[y] = run;
+                run += n;
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && counts)
+            counts[f] = s_total;
+        for (int it = 0; it < sweeps; it++) {
+            const FrameSpan c = frame_span(it, h, w32);
+            const int yy = c.y < h ? c.y : 0;
+            rank_span(fbits + (size_t)yy * w32, L, c.y, w, c.w0, c.w1, c.lane, c.valid,
+                      c.valid ? s_rowbase[c.y] : 0);
+        }
+        return;
+    }
+
+    // ---- 2. singleton trees ----------------------------------------------------------------------
+    for (int i = tid; i < nruns; i += kFrameThreads)
+        s_parent[i] = i;
+    __syncthreads();
+
+    // ---- 3. link runs of row y with runs of row y-1 -----------------------------------------------
+    for (int it = 0; it < sweeps; it++) {
+        const FrameSpan c = frame_span(it, h, w32);
+        const bool act = c.valid && c.y > 0;
+        const uint32_t *row = fbits + (size_t)(act ? c.y : 1) * w32;
+        const uint32_t *up = row - w32;
+        int nc = act ? count_starts(row, c.w0, c.w1) : 0;
+        int nu = act ? count_starts(up, c.w0, c.w1) : 0;
+        // runs of the row that start left of this lane's span
+        int cc = row_prefix(nc, c.lane), cu = row_prefix(nu, c.lane);
+        if (!act)
+            continue;
+        cc += s_rowbase[c.y] - 1;        // id of the run that holds pixel x = cc + starts in the
+        cu += s_rowbase[c.y - 1] - 1;    // span at or left of x (same for the row above)
+        uint32_t mp = c.w0 > 0 ? row[c.w0 - 1] : 0u, upv = c.w0 > 0 ? up[c.w0 - 1] : 0u;
+        for (int wi = c.w0; wi < c.w1; wi++) {
+            const uint32_t m = row[wi], u = up[wi];
+            const uint32_t sc = m & ~((m << 1) | (mp >> 31)), su = u & ~((u << 1) | (upv >> 31));
+            // vertical contacts: one union per maximal run of (m & u)
+            const uint32_t v = m & u;
+            uint32_t vs = v & ~((v << 1) | ((mp & upv) >> 31));
+            while (vs) {
+                const int b = __ffs(vs) - 1;
+                vs &= vs - 1;
+                lds_unite(s_parent, cc + __popc(sc & upto(b)), cu + __popc(su & upto(b)));
+            }
+            if (CONN8) {
+                const uint32_t mn = wi + 1 < w32 ? row[wi + 1] : 0u, un = wi + 1 < w32 ? up[wi + 1] : 0u;
+                // (y,x) ~ (y-1,x+1), needed only if neither (y-1,x) nor (y,x+1) is set; (y-1,x)
+                // is background, so (y-1,x+1) starts the run after the starts at or left of x
+                const uint32_t uR = (u >> 1) | (un << 31), mR = (m >> 1) | (mn << 31);
+                uint32_t dr = m & uR & ~u & ~mR;
+                while (dr) {
+                    const int b = __ffs(dr) - 1;
+                    dr &= dr - 1;
+                    lds_unite(s_parent, cc + __popc(sc & upto(b)), cu + __popc(su & upto(b)) + 1);
+                }
+                // (y,x) ~ (y-1,x-1), needed only if neither (y-1,x) nor (y,x-1) is set: no run
+                // of the row above starts at x, so the run holding x-1 is the last start <= x
+                const uint32_t uL = (u << 1) | (upv >> 31), mL = (m << 1) | (mp >> 31);
+                uint32_t dl = m & uL & ~u & ~mL;
+                while (dl) {
+                    const int b = __ffs(dl) - 1;
+                    dl &= dl - 1;
+                    lds_unite(s_parent, cc + __popc(sc & upto(b)), cu + __popc(su & upto(b)));
+                }
+            }
+            cc += __popc(sc);
+            cu += __popc(su);
+            mp = m;
+            upv = u;
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. flatten, rank the roots in id (= raster) order -----------------------------------------
+    const int ids_per_thread = (nruns + kFrameThreads - 1) / kFrameThreads;
+    const int i0 = min(nruns, tid * ids_per_thread), i1 = min(nruns, i0 + ids_per_thread);
+    int nroots = 0;
+    for (int i = i0; i < i1; i++) {
+        const int r = lds_find_root_ro(s_parent, i);
+        if (r == i)
+            nroots++;
+        else
+            lds_st(s_parent + i, r);
+    }
+    __syncthreads();                       // every parent is final (a root or a root's id)
+    int k = block_exclusive_scan(nroots, s_part, &s_total);
+    if (tid == 0 && counts)
+        counts[f] = s_total;
+    for (int i = i0; i < i1; i++)
+        if (s_parent[i] == i)
+            s_parent[i] = -(++k);          // roots: -(label); only this thread touches entry i
+    __syncthreads();
+
+    // ---- 5. one sparse write per run: what the paint pass and the contour tracer read ---------------
+    for (int it = 0; it < sweeps; it++) {
+        const FrameSpan c = frame_span(it, h, w32);
+        const uint32_t *row = fbits + (size_t)(c.valid ? c.y : 0) * w32;
+        const int nc = c.valid ? count_starts(row, c.w0, c.w1) : 0;
+        int id = row_prefix(nc, c.lane);
+        if (!c.valid)
+            continue;
+        id += s_rowbase[c.y];
+        int32_t *out = L + (size_t)c.y * w;
+        uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
+        for (int wi = c.w0; wi < c.w1; wi++) {
+            const uint32_t m = row[wi];
+            uint32_t sc = m & ~((m << 1) | prev);
+            prev = m >> 31;
+            while (sc) {
+                const int b = __ffs(sc) - 1;
+                sc &= sc - 1;
+                int v = s_parent[id++];
+                if (v >= 0)
+                    v = -((-s_parent[v]) | kNonRootBit);
+                out[(wi << 5) + b] = v;
+            }
+        }
+    }
+}
+
 
 // ---- K6: paint the label image (one coalesced write), optional per-label statistics ---------
 __device__ __forceinline__ void stats_add(int64_t *st, int y, int xs, int len)
@@ -431,13 +790,13 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                         int v = L[c.y * w + start];
                         if (v >= 0)
                             v = L[v];
-                        lab = v < 0 ? -v : v;
+                        lab = (v < 0 ? -v : v) & (kNonRootBit - 1);
                     }
                 } else {
                     int v = L[c.y * w + (wi << 5) + b];
                     if (v >= 0)
                         v = L[v];  // root entry: -label, or +label if its row is already painted
-                    lab = v < 0 ? -v : v;
+                    lab = (v < 0 ? -v : v) & (kNonRootBit - 1);   // per-frame kernel: bit 30 = not a root
                 }
                 s_lab[wv][c.lane][k++] = lab;
                 last_label = lab;
@@ -686,7 +1045,8 @@ contour_areas_kernel(const uint32_t *__restrict__ bits, const int32_t *__restric
             const int b = __ffs(s) - 1;
             s &= s - 1;
             const int x = (wi << 5) + b, idx = c.y * w + x;
-            if (L[idx] >= 0)
+            const int v = L[idx];
+            if (v >= 0 || (-v & kNonRootBit))
                 continue;   // not a component's first pixel
             AreaEmit e;
             trace_outer_border(im, x, c.y, e);
@@ -739,6 +1099,14 @@ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_
 
 }  // namespace
 
+// the per-frame LDS kernel labels frames of up to kLdsRows rows; VA_CCL_LEGACY=1 (test hook)
+// forces the chip-wide multi-pass path, which taller frames always take
+bool ccl_frame_kernel_used(int h)
+{
+    const char *e = getenv("VA_CCL_LEGACY");
+    return h <= kLdsRows && !(e && atoi(e) != 0);
+}
+
 size_t ccl_workspace_bytes(int n, int h, int w)
 {
     // [bit mask for the u8 entry point][row_cnt][row_off]
@@ -773,26 +1141,40 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     const int grid = cdiv((long long)total_rows, kRowsPerBlock);          // paint: wave = row
     const int sgrid = cdiv((long long)total_rows, kSparseRowsPerBlock);   // sparse: wave = 8 rows
 
-    if (!forest_ready) {
-        ccl_init_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
-        VA_LAUNCH_CHECK("ccl_init_kernel");
-        VA_MARK("ccl_init");
+    if (ccl_frame_kernel_used(h)) {
+        // one workgroup per frame, forest in LDS (falls back to the label image inside the kernel
+        // for frames with more runs than the table holds)
+        int lds_runs = kLdsRuns;
+        if (const char *e = getenv("VA_CCL_LDS_RUNS"))    // test hook: force the large-frame mode
+            lds_runs = max(0, min(kLdsRuns, atoi(e)));
+        if (connectivity == 8)
+            ccl_frame_kernel<true><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lds_runs);
+        else
+            ccl_frame_kernel<false><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lds_runs);
+        VA_LAUNCH_CHECK("ccl_frame_kernel");
+        VA_MARK("ccl_frame");
+    } else {
+        if (!forest_ready) {
+            ccl_init_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+            VA_LAUNCH_CHECK("ccl_init_kernel");
+            VA_MARK("ccl_init");
+        }
+        if (connectivity == 8)
+            ccl_link_kernel<true><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+        else
+            ccl_link_kernel<false><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
+        VA_LAUNCH_CHECK("ccl_link_kernel");
+        VA_MARK("ccl_link");
+        ccl_flatten_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_cnt, h, w, w32, total_rows);
+        VA_LAUNCH_CHECK("ccl_flatten_kernel");
+        VA_MARK("ccl_flatten");
+        ccl_rowscan_kernel<<<n, kBlock, 0, st>>>(row_cnt, row_off, counts, h);
+        VA_LAUNCH_CHECK("ccl_rowscan_kernel");
+        VA_MARK("ccl_rowscan");
+        ccl_rank_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, total_rows);
+        VA_LAUNCH_CHECK("ccl_rank_kernel");
+        VA_MARK("ccl_rank");
     }
-    if (connectivity == 8)
-        ccl_link_kernel<true><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
-    else
-        ccl_link_kernel<false><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
-    VA_LAUNCH_CHECK("ccl_link_kernel");
-    VA_MARK("ccl_link");
-    ccl_flatten_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_cnt, h, w, w32, total_rows);
-    VA_LAUNCH_CHECK("ccl_flatten_kernel");
-    VA_MARK("ccl_flatten");
-    ccl_rowscan_kernel<<<n, kBlock, 0, st>>>(row_cnt, row_off, counts, h);
-    VA_LAUNCH_CHECK("ccl_rowscan_kernel");
-    VA_MARK("ccl_rowscan");
-    ccl_rank_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, total_rows);
-    VA_LAUNCH_CHECK("ccl_rank_kernel");
-    VA_MARK("ccl_rank");
     if (!paint)
         return VA_OK;
     const int vec = (w % 4 == 0) && aligned(labels, 16);
