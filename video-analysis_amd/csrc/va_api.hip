@@ -846,7 +846,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     bool forest_ready = false;
     if (c.morph_count > 0 && morph_fused_supported(c.width, p->se, c.morph_count)) {
         // the chip-wide labelling path wants its forest planted by the last morphology op
-        int32_t *plant = ccl_frame_kernel_used(c.height) ? nullptr : labels;
+        int32_t *plant = ccl_frame_kernel_used(c.height, c.width) ? nullptr : labels;
         rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], plant, n, c.height, c.width, c.morph_op,
                                 p->se, c.morph_count, st);
         if (rc)

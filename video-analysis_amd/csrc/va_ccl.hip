@@ -394,20 +394,46 @@ ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
 //   * runs get COMPACT ids in raster order: id = (runs in earlier rows, from an exclusive scan
 //     of per-row run counts) + (run starts at or left of the pixel, by popcounts) - 1.  No
 //     backward search for a run's first pixel, no node in global memory;
-//   * unions are ds_min atomics towards the smaller id, so the root is again the component's
+//   * every wave sweeps 8 rows at a time: the rows (contiguous in memory) are copied into the
+//     wave's LDS stage with coalesced 16-byte loads, lanes (row, word group) then work on LDS;
+//   * contacts between rows are first QUEUED per wave, then united with all lanes busy
+//     (in-place unions serialise: a wave runs the longest lane's chain at every word);
+//     unions are ds_min atomics towards the smaller id, so the root is again the component's
 //     first run in raster order and label = 1 + number of roots with a smaller id;
-//   * the only global traffic is the bit mask (L2-resident, read four times) and one sparse
-//     write per run: -(label) at the run's first pixel (bit 30 set for runs that are not their
-//     component's first), which is exactly what ccl_paint_kernel / the contour tracer consume.
+//   * the only global traffic is the bit mask (read three times, L2-resident after the first)
+//     and one sparse write per run: -(label) at the run's first pixel (bit 30 set for runs that
+//     are not their component's first), which is what ccl_paint_kernel / the contour tracer read.
 // Frames with more runs than the LDS table holds (noise, checkerboards) are labelled by the
 // same workgroup with the forest in the label image (the *_span bodies above): same result,
 // one CU per frame.
 constexpr int kFrameThreads = 1024;
 constexpr int kFrameWaves = kFrameThreads / kWave;                // 16
 constexpr int kFrameRowsPerIter = kFrameWaves * kRowsPerWave;     // 128 rows per sweep step
-constexpr int kLdsRuns = 32768;                                   // 128 KB of parents
-constexpr int kLdsRows = 4400;                                    // row table (8K-tall frames: legacy)
+constexpr int kFrameLdsWords = 37 * 1024;                         // 148 KB, partitioned per launch
+constexpr int kQueue = 128;                                       // queued pairs per wave
+constexpr int kMinLdsRuns = 4096;                                 // else: chip-wide path
 constexpr int kNonRootBit = 1 << 30;
+
+constexpr int kChunk = 8;                                         // words per lane and chunk
+constexpr int kStagePad = 4;                                      // zero words left of a staged row
+
+struct FrameLayout {   // word offsets into the kernel's LDS array
+    int row_stride;    // staged row: kStagePad zeros, the row, zeros up to 8 lanes x chunks + 4
+    int stage_words;   // per wave: 9 staged rows of the mask
+    int queue_off, rowbase_off, parent_off, lds_runs;
+};
+inline int span_chunks(int w32) { return (((w32 + 7) >> 3) + kChunk - 1) / kChunk; }
+inline FrameLayout frame_layout(int h, int w32)
+{
+    FrameLayout l;
+    l.row_stride = kStagePad + 8 * span_chunks(w32) * kChunk + 4;
+    l.stage_words = (kRowsPerWave + 1) * l.row_stride;
+    l.queue_off = kFrameWaves * l.stage_words;
+    l.rowbase_off = l.queue_off + kFrameWaves * 2 * kQueue;
+    l.parent_off = l.rowbase_off + ((h + 1 + 3) & ~3);
+    l.lds_runs = kFrameLdsWords - l.parent_off;
+    return l;
+}
 
 __device__ __forceinline__ int lds_ld(const int *p)
 {
@@ -458,32 +484,53 @@ __device__ __forceinline__ void lds_unite(int *P, int a, int b)
     }
 }
 
+// LDS traffic between the lanes of ONE wave: DS instructions of a wave execute in program
+// order, so only the compiler has to be kept from reordering them
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct FrameSpan {
-    bool valid;   // this lane has a row of the frame and a non-empty word span
-    int lane, y, w0, w1;
+    bool valid;   // this lane has a row of the frame
+    int lane, r, y, w0, w1;   // word span [w0, w1): NCH whole chunks (zero-padded in the stage)
 };
-__device__ __forceinline__ FrameSpan frame_span(int it, int h, int w32)
+template <int NCH>
+__device__ __forceinline__ FrameSpan frame_span(int y0, int h, int w32)
 {
     FrameSpan c;
     c.lane = threadIdx.x & (kWave - 1);
-    c.y = it * kFrameRowsPerIter + (int)(threadIdx.x >> 6) * kRowsPerWave + (c.lane & (kRowsPerWave - 1));
-    const int g = c.lane >> 3, G = (w32 + 7) >> 3;
-    c.w0 = g * G;
-    c.w1 = min(w32, c.w0 + G);
-    c.valid = c.y < h && c.w0 < c.w1;
+    c.r = c.lane & (kRowsPerWave - 1);
+    c.y = y0 + c.r;
+    c.w0 = (c.lane >> 3) * NCH * kChunk;
+    c.w1 = min(w32, c.w0 + NCH * kChunk);    // large-frame mode reads global memory: real bounds
+    c.valid = c.y < h;
     return c;
 }
 
-// run starts in a span of a row
-__device__ __forceinline__ int count_starts(const uint32_t *row, int w0, int w1)
+// NCH chunks of a staged row starting at word w0, each with the word on either side:
+// m[j][0] = word c0-1, m[j][1 + k] = word c0 + k; the stage is zero outside the row
+template <int NCH>
+__device__ __forceinline__ void load_span(const int *row, int w0, uint32_t (&m)[NCH][kChunk + 2])
+{
+#pragma unroll
+    for (int j = 0; j < NCH; j++)
+#pragma unroll
+        for (int k = 0; k < kChunk + 2; k++)
+            m[j][k] = (uint32_t)row[w0 + j * kChunk - 1 + k];
+}
+
+// run starts in the span
+template <int NCH>
+__device__ __forceinline__ int count_starts(const uint32_t (&m)[NCH][kChunk + 2])
 {
     int n = 0;
-    uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
-    for (int wi = w0; wi < w1; wi++) {
-        const uint32_t m = row[wi];
-        n += __popc(m & ~((m << 1) | prev));
-        prev = m >> 31;
-    }
+#pragma unroll
+    for (int j = 0; j < NCH; j++)
+#pragma unroll
+        for (int k = 0; k < kChunk; k++)
+            n += __popc(m[j][k + 1] & ~((m[j][k + 1] << 1) | (m[j][k] >> 31)));
     return n;
 }
 
@@ -517,148 +564,224 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *s_part, int *tot
     return before + incl - v;
 }
 
-template <bool CONN8>
+// in place: per-row counts -> exclusive prefix; returns the total through *total
+__device__ __forceinline__ void scan_rows(int *rowbase, int h, int *s_part, int *total)
+{
+    const int per = (h + kFrameThreads - 1) / kFrameThreads;
+    const int y0 = min(h, (int)threadIdx.x * per), y1 = min(h, y0 + per);
+    int sum = 0;
+    for (int y = y0; y < y1; y++)
+        sum += rowbase[y];
+    int run = block_exclusive_scan(sum, s_part, total);
+    for (int y = y0; y < y1; y++) {
+        const int n = rowbase[y];
+        rowbase[y] = run;
+        run += n;
+    }
+    __syncthreads();
+}
+
+template <bool CONN8, int NCH>
 __global__ void __launch_bounds__(kFrameThreads)
 ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
-                 int32_t *__restrict__ counts, int h, int w, int w32, int lds_runs)
+                 int32_t *__restrict__ counts, int h, int w, int w32, FrameLayout lay, int vec)
 {
-    __shared__ int s_parent[kLdsRuns];
-    __shared__ int s_rowbase[kLdsRows];
+    __shared__ __attribute__((aligned(16))) int s_mem[kFrameLdsWords];
     __shared__ int s_part[kFrameWaves];
+    __shared__ int s_qcnt[kFrameWaves];
     __shared__ int s_total;
 
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & (kWave - 1);
     const uint32_t *fbits = bits + (size_t)f * h * w32;
     int32_t *L = labels + (size_t)f * h * w;
+    int *stage = s_mem + wv * lay.stage_words + kStagePad;   // slot j <-> image row y0 - 1 + j
+    const int rs = lay.row_stride;
+    for (int i = lane; i < lay.stage_words; i += kWave)       // the pads stay zero for good
+        stage[i - kStagePad] = 0;
+    int *queue = s_mem + lay.queue_off + wv * 2 * kQueue;
+    int *rowbase = s_mem + lay.rowbase_off;
+    int *parent = s_mem + lay.parent_off;
     const int sweeps = (h + kFrameRowsPerIter - 1) / kFrameRowsPerIter;
-    const int rows_per_thread = (h + kFrameThreads - 1) / kFrameThreads;
-    const int ty0 = min(h, tid * rows_per_thread), ty1 = min(h, ty0 + rows_per_thread);
+    if (lane == 0)
+        s_qcnt[wv] = 0;
+
+    // stage image rows y0 - 1 ... y0 + 7 of this wave's sweep step (slot 0 is the row above y0).
+    // All nine loads are issued before any is used -- one memory round trip per sweep step --
+    // from clamped, always valid addresses: slots of rows outside the frame hold a copy of an
+    // edge row, and no lane that reads them is `valid`.
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto stage_rows = [&](int y0) {
+        if (vec) {
+            const int col = min(lane * 4, w32 - 4);
+            v4i t[kRowsPerWave + 1];
+#pragma unroll
+            for (int j = 0; j <= kRowsPerWave; j++) {
+                const int y = min(max(y0 - 1 + j, 0), h - 1);
+                t[j] = *reinterpret_cast<const v4i *>(fbits + (size_t)y * w32 + col);
+            }
+            wave_sync();                                // earlier readers of the stage are done
+            if (lane * 4 < w32) {
+#pragma unroll
+                for (int j = 0; j <= kRowsPerWave; j++)
+                    *reinterpret_cast<v4i *>(stage + j * rs + lane * 4) = t[j];
+            }
+        } else {
+            const int c0 = min(lane, w32 - 1), c1 = min(lane + kWave, w32 - 1);   // w32 <= 128
+            int t0[kRowsPerWave + 1], t1[kRowsPerWave + 1];
+#pragma unroll
+            for (int j = 0; j <= kRowsPerWave; j++) {
+                const uint32_t *src = fbits + (size_t)min(max(y0 - 1 + j, 0), h - 1) * w32;
+                t0[j] = (int)src[c0];
+                t1[j] = (int)src[c1];
+            }
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j <= kRowsPerWave; j++) {
+                if (lane < w32)
+                    stage[j * rs + lane] = t0[j];
+                if (lane + kWave < w32)
+                    stage[j * rs + lane + kWave] = t1[j];
+            }
+        }
+        wave_sync();
+    };
 
     // ---- 1. runs per row, exclusive scan -> first run id of every row -----------------------
     for (int it = 0; it < sweeps; it++) {
-        const FrameSpan c = frame_span(it, h, w32);
-        int n = c.valid ? count_starts(fbits + (size_t)c.y * w32, c.w0, c.w1) : 0;
+        const int y0 = it * kFrameRowsPerIter + wv * kRowsPerWave;
+        stage_rows(y0);
+        const FrameSpan c = frame_span<NCH>(y0, h, w32);
+        uint32_t mw[NCH][kChunk + 2];
+        load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
+        int n = c.valid ? count_starts<NCH>(mw) : 0;
         n = row_sum(n);
-        if (c.lane < kRowsPerWave && c.y < h)
-            s_rowbase[c.y] = n;
+        if (lane < kRowsPerWave && c.y < h)
+            rowbase[c.y] = n;
     }
     __syncthreads();
-    {
-        int sum = 0;
-        for (int y = ty0; y < ty1; y++)
-            sum += s_rowbase[y];
-        int run = block_exclusive_scan(sum, s_part, &s_total);
-        for (int y = ty0; y < ty1; y++) {
-            const int n = s_rowbase[y];
-            s_rowbase[y] = run;
-            run += n;
-        }
-    }
-    __syncthreads();
+    scan_rows(rowbase, h, s_part, &s_total);
     const int nruns = s_total;
 
-    if (nruns > lds_runs) {
+    if (nruns > lay.lds_runs) {
         // ---- large-frame mode: forest in the label image, same passes as the chip-wide path ---
         for (int it = 0; it < sweeps; it++) {
-            const FrameSpan c = frame_span(it, h, w32);
-            if (c.valid)
+            const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
+            if (c.valid && c.w0 < c.w1)
                 init_span(fbits + (size_t)c.y * w32, L, c.y, w, c.w0, c.w1);
         }
         __syncthreads();
         for (int it = 0; it < sweeps; it++) {
-            const FrameSpan c = frame_span(it, h, w32);
-            if (c.valid && c.y > 0)
+            const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
+            if (c.valid && c.w0 < c.w1 && c.y > 0)
                 link_span<CONN8>(fbits + (size_t)c.y * w32, L, c.y, w, w32, c.w0, c.w1);
         }
         __syncthreads();
         for (int it = 0; it < sweeps; it++) {
-            const FrameSpan c = frame_span(it, h, w32);
-            int n = c.valid ? flatten_span(fbits + (size_t)c.y * w32, L, c.y, w, c.w0, c.w1) : 0;
+            const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
+            int n = c.valid && c.w0 < c.w1 ? flatten_span(fbits + (size_t)c.y * w32, L, c.y, w, c.w0, c.w1) : 0;
             n = row_sum(n);
-            if (c.lane < kRowsPerWave && c.y < h)
-                s_rowbase[c.y] = n;
+            if (lane < kRowsPerWave && c.y < h)
+                rowbase[c.y] = n;
         }
         __syncthreads();
-        {
-            int sum = 0;
-            for (int y = ty0; y < ty1; y++)
-                sum += s_rowbase[y];
-            int run = block_exclusive_scan(sum, s_part, &s_total);
-            for (int y = ty0; y < ty1; y++) {
-                const int n = s_rowbase[y];
-                s_rowbase[y] = run;
-                run += n;
-            }
-        }
-        __syncthreads();
+        scan_rows(rowbase, h, s_part, &s_total);
         if (tid == 0 && counts)
             counts[f] = s_total;
         for (int it = 0; it < sweeps; it++) {
-            const FrameSpan c = frame_span(it, h, w32);
+            const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
             const int yy = c.y < h ? c.y : 0;
-            rank_span(fbits + (size_t)yy * w32, L, c.y, w, c.w0, c.w1, c.lane, c.valid,
-                      c.valid ? s_rowbase[c.y] : 0);
+            const bool ok = c.valid && c.w0 < c.w1;
+            rank_span(fbits + (size_t)yy * w32, L, c.y, w, c.w0, c.w1, lane, ok,
+                      ok ? rowbase[c.y] : 0);
         }
         return;
     }
 
     // ---- 2. singleton trees ----------------------------------------------------------------------
     for (int i = tid; i < nruns; i += kFrameThreads)
-        s_parent[i] = i;
+        parent[i] = i;
     __syncthreads();
+
+    // a pair for the wave's queue; when the queue is full the caller acts on it at once
+    auto push = [&](int a, int b) -> bool {
+        const int slot = atomicAdd(&s_qcnt[wv], 1);
+        if (slot >= kQueue)
+            return false;
+        queue[2 * slot] = a;
+        queue[2 * slot + 1] = b;
+        return true;
+    };
 
     // ---- 3. link runs of row y with runs of row y-1 -----------------------------------------------
     for (int it = 0; it < sweeps; it++) {
-        const FrameSpan c = frame_span(it, h, w32);
+        const int y0 = it * kFrameRowsPerIter + wv * kRowsPerWave;
+        stage_rows(y0);
+        const FrameSpan c = frame_span<NCH>(y0, h, w32);
         const bool act = c.valid && c.y > 0;
-        const uint32_t *row = fbits + (size_t)(act ? c.y : 1) * w32;
-        const uint32_t *up = row - w32;
-        int nc = act ? count_starts(row, c.w0, c.w1) : 0;
-        int nu = act ? count_starts(up, c.w0, c.w1) : 0;
+        uint32_t mw[NCH][kChunk + 2], uw[NCH][kChunk + 2];
+        load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
+        load_span<NCH>(stage + c.r * rs, c.w0, uw);
+        const int nc = act ? count_starts<NCH>(mw) : 0;
+        const int nu = act ? count_starts<NCH>(uw) : 0;
         // runs of the row that start left of this lane's span
-        int cc = row_prefix(nc, c.lane), cu = row_prefix(nu, c.lane);
-        if (!act)
-            continue;
-        cc += s_rowbase[c.y] - 1;        // id of the run that holds pixel x = cc + starts in the
-        cu += s_rowbase[c.y - 1] - 1;    // span at or left of x (same for the row above)
-        uint32_t mp = c.w0 > 0 ? row[c.w0 - 1] : 0u, upv = c.w0 > 0 ? up[c.w0 - 1] : 0u;
-        for (int wi = c.w0; wi < c.w1; wi++) {
-            const uint32_t m = row[wi], u = up[wi];
-            const uint32_t sc = m & ~((m << 1) | (mp >> 31)), su = u & ~((u << 1) | (upv >> 31));
-            // vertical contacts: one union per maximal run of (m & u)
-            const uint32_t v = m & u;
-            uint32_t vs = v & ~((v << 1) | ((mp & upv) >> 31));
-            while (vs) {
-                const int b = __ffs(vs) - 1;
-                vs &= vs - 1;
-                lds_unite(s_parent, cc + __popc(sc & upto(b)), cu + __popc(su & upto(b)));
-            }
-            if (CONN8) {
-                const uint32_t mn = wi + 1 < w32 ? row[wi + 1] : 0u, un = wi + 1 < w32 ? up[wi + 1] : 0u;
-                // (y,x) ~ (y-1,x+1), needed only if neither (y-1,x) nor (y,x+1) is set; (y-1,x)
-                // is background, so (y-1,x+1) starts the run after the starts at or left of x
-                const uint32_t uR = (u >> 1) | (un << 31), mR = (m >> 1) | (mn << 31);
-                uint32_t dr = m & uR & ~u & ~mR;
-                while (dr) {
-                    const int b = __ffs(dr) - 1;
-                    dr &= dr - 1;
-                    lds_unite(s_parent, cc + __popc(sc & upto(b)), cu + __popc(su & upto(b)) + 1);
+        int cc = row_prefix(nc, lane), cu = row_prefix(nu, lane);
+        if (act) {
+            cc += rowbase[c.y] - 1;        // id of the run that holds pixel x = cc + starts in the
+            cu += rowbase[c.y - 1] - 1;    // span at or left of x (same for the row above)
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+#pragma unroll
+                for (int k = 0; k < kChunk; k++) {
+                    const uint32_t mp = mw[j][k], m = mw[j][k + 1], upv = uw[j][k], u = uw[j][k + 1];
+                    const uint32_t sc = m & ~((m << 1) | (mp >> 31)), su = u & ~((u << 1) | (upv >> 31));
+                    // vertical contacts: one union per maximal run of (m & u)
+                    const uint32_t v = m & u;
+                    uint32_t vs = v & ~((v << 1) | ((mp & upv) >> 31));
+                    while (vs) {
+                        const int b = __ffs(vs) - 1;
+                        vs &= vs - 1;
+                        const int ia = cc + __popc(sc & upto(b)), ib = cu + __popc(su & upto(b));
+                        if (!push(ia, ib))
+                            lds_unite(parent, ia, ib);
+                    }
+                    if (CONN8) {
+                        const uint32_t mn = mw[j][k + 2], un = uw[j][k + 2];
+                        // (y,x) ~ (y-1,x+1), needed only if neither (y-1,x) nor (y,x+1) is set;
+                        // (y-1,x) is background, so (y-1,x+1) starts the run after the starts <= x
+                        const uint32_t uR = (u >> 1) | (un << 31), mR = (m >> 1) | (mn << 31);
+                        uint32_t dr = m & uR & ~u & ~mR;
+                        while (dr) {
+                            const int b = __ffs(dr) - 1;
+                            dr &= dr - 1;
+                            const int ia = cc + __popc(sc & upto(b)), ib = cu + __popc(su & upto(b)) + 1;
+                            if (!push(ia, ib))
+                                lds_unite(parent, ia, ib);
+                        }
+                        // (y,x) ~ (y-1,x-1), needed only if neither (y-1,x) nor (y,x-1) is set: no
+                        // run of the row above starts at x, so x-1 is in the run of the last start <= x
+                        const uint32_t uL = (u << 1) | (upv >> 31), mL = (m << 1) | (mp >> 31);
+                        uint32_t dl = m & uL & ~u & ~mL;
+                        while (dl) {
+                            const int b = __ffs(dl) - 1;
+                            dl &= dl - 1;
+                            const int ia = cc + __popc(sc & upto(b)), ib = cu + __popc(su & upto(b));
+                            if (!push(ia, ib))
+                                lds_unite(parent, ia, ib);
+                        }
+                    }
+                    cc += __popc(sc);
+                    cu += __popc(su);
                 }
-                // (y,x) ~ (y-1,x-1), needed only if neither (y-1,x) nor (y,x-1) is set: no run
-                // of the row above starts at x, so the run holding x-1 is the last start <= x
-                const uint32_t uL = (u << 1) | (upv >> 31), mL = (m << 1) | (mp >> 31);
-                uint32_t dl = m & uL & ~u & ~mL;
-                while (dl) {
-                    const int b = __ffs(dl) - 1;
-                    dl &= dl - 1;
-                    lds_unite(s_parent, cc + __popc(sc & upto(b)), cu + __popc(su & upto(b)));
-                }
             }
-            cc += __popc(sc);
-            cu += __popc(su);
-            mp = m;
-            upv = u;
         }
+        // drain: every lane takes queued contacts, so the wave runs one union chain deep
+        wave_sync();
+        const int nq = min(lds_ld(&s_qcnt[wv]), kQueue);
+        for (int i = lane; i < nq; i += kWave)
+            lds_unite(parent, queue[2 * i], queue[2 * i + 1]);
+        wave_sync();
+        if (lane == 0)
+            lds_st(&s_qcnt[wv], 0);
     }
     __syncthreads();
 
@@ -667,48 +790,64 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     const int i0 = min(nruns, tid * ids_per_thread), i1 = min(nruns, i0 + ids_per_thread);
     int nroots = 0;
     for (int i = i0; i < i1; i++) {
-        const int r = lds_find_root_ro(s_parent, i);
+        const int r = lds_find_root_ro(parent, i);
         if (r == i)
             nroots++;
         else
-            lds_st(s_parent + i, r);
+            lds_st(parent + i, r);
     }
     __syncthreads();                       // every parent is final (a root or a root's id)
     int k = block_exclusive_scan(nroots, s_part, &s_total);
     if (tid == 0 && counts)
         counts[f] = s_total;
     for (int i = i0; i < i1; i++)
-        if (s_parent[i] == i)
-            s_parent[i] = -(++k);          // roots: -(label); only this thread touches entry i
+        if (parent[i] == i)
+            parent[i] = -(++k);            // roots: -(label); only this thread touches entry i
     __syncthreads();
 
     // ---- 5. one sparse write per run: what the paint pass and the contour tracer read ---------------
+    auto emit = [&](int pix, int id) {
+        int v = parent[id];
+        if (v >= 0)
+            v = -((-parent[v]) | kNonRootBit);
+        L[pix] = v;
+    };
     for (int it = 0; it < sweeps; it++) {
-        const FrameSpan c = frame_span(it, h, w32);
-        const uint32_t *row = fbits + (size_t)(c.valid ? c.y : 0) * w32;
-        const int nc = c.valid ? count_starts(row, c.w0, c.w1) : 0;
-        int id = row_prefix(nc, c.lane);
-        if (!c.valid)
-            continue;
-        id += s_rowbase[c.y];
-        int32_t *out = L + (size_t)c.y * w;
-        uint32_t prev = c.w0 > 0 ? row[c.w0 - 1] >> 31 : 0u;
-        for (int wi = c.w0; wi < c.w1; wi++) {
-            const uint32_t m = row[wi];
-            uint32_t sc = m & ~((m << 1) | prev);
-            prev = m >> 31;
-            while (sc) {
-                const int b = __ffs(sc) - 1;
-                sc &= sc - 1;
-                int v = s_parent[id++];
-                if (v >= 0)
-                    v = -((-s_parent[v]) | kNonRootBit);
-                out[(wi << 5) + b] = v;
+        const int y0 = it * kFrameRowsPerIter + wv * kRowsPerWave;
+        stage_rows(y0);
+        const FrameSpan c = frame_span<NCH>(y0, h, w32);
+        uint32_t mw[NCH][kChunk + 2];
+        load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
+        const int nc = c.valid ? count_starts<NCH>(mw) : 0;
+        int id = row_prefix(nc, lane);
+        if (c.valid) {
+            id += rowbase[c.y];
+            const int base = c.y * w + (c.w0 << 5);
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+#pragma unroll
+                for (int k = 0; k < kChunk; k++) {
+                    uint32_t sc = mw[j][k + 1] & ~((mw[j][k + 1] << 1) | (mw[j][k] >> 31));
+                    while (sc) {
+                        const int b = __ffs(sc) - 1;
+                        sc &= sc - 1;
+                        const int pix = base + ((j * kChunk + k) << 5) + b;
+                        if (!push(pix, id))
+                            emit(pix, id);
+                        id++;
+                    }
+                }
             }
         }
+        wave_sync();
+        const int nq = min(lds_ld(&s_qcnt[wv]), kQueue);
+        for (int i = lane; i < nq; i += kWave)
+            emit(queue[2 * i], queue[2 * i + 1]);
+        wave_sync();
+        if (lane == 0)
+            lds_st(&s_qcnt[wv], 0);
     }
 }
-
 
 // ---- K6: paint the label image (one coalesced write), optional per-label statistics ---------
 __device__ __forceinline__ void stats_add(int64_t *st, int y, int xs, int len)
@@ -1099,12 +1238,15 @@ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_
 
 }  // namespace
 
-// the per-frame LDS kernel labels frames of up to kLdsRows rows; VA_CCL_LEGACY=1 (test hook)
-// forces the chip-wide multi-pass path, which taller frames always take
-bool ccl_frame_kernel_used(int h)
+// the per-frame LDS kernel takes frames whose row table and row stages leave room for at least
+// kMinLdsRuns runs; VA_CCL_LEGACY=1 (test hook) forces the chip-wide multi-pass path
+bool ccl_frame_kernel_used(int h, int w)
 {
     const char *e = getenv("VA_CCL_LEGACY");
-    return h <= kLdsRows && !(e && atoi(e) != 0);
+    if (e && atoi(e) != 0)
+        return false;
+    const int w32 = words_per_row(w);
+    return span_chunks(w32) <= 2 && frame_layout(h, w32).lds_runs >= kMinLdsRuns;
 }
 
 size_t ccl_workspace_bytes(int n, int h, int w)
@@ -1141,16 +1283,27 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     const int grid = cdiv((long long)total_rows, kRowsPerBlock);          // paint: wave = row
     const int sgrid = cdiv((long long)total_rows, kSparseRowsPerBlock);   // sparse: wave = 8 rows
 
-    if (ccl_frame_kernel_used(h)) {
+    if (ccl_frame_kernel_used(h, w)) {
         // one workgroup per frame, forest in LDS (falls back to the label image inside the kernel
         // for frames with more runs than the table holds)
-        int lds_runs = kLdsRuns;
+        FrameLayout lay = frame_layout(h, w32);
         if (const char *e = getenv("VA_CCL_LDS_RUNS"))    // test hook: force the large-frame mode
-            lds_runs = max(0, min(kLdsRuns, atoi(e)));
-        if (connectivity == 8)
-            ccl_frame_kernel<true><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lds_runs);
-        else
-            ccl_frame_kernel<false><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lds_runs);
+            lay.lds_runs = max(0, min(lay.lds_runs, atoi(e)));
+        const int vec = (w32 % 4 == 0) && aligned(bits, 16);
+#define VA_FRAME_LAUNCH(C8, NCH) \
+    ccl_frame_kernel<C8, NCH><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, vec)
+        if (span_chunks(w32) == 1) {
+            if (connectivity == 8)
+                VA_FRAME_LAUNCH(true, 1);
+            else
+                VA_FRAME_LAUNCH(false, 1);
+        } else {
+            if (connectivity == 8)
+                VA_FRAME_LAUNCH(true, 2);
+            else
+                VA_FRAME_LAUNCH(false, 2);
+        }
+#undef VA_FRAME_LAUNCH
         VA_LAUNCH_CHECK("ccl_frame_kernel");
         VA_MARK("ccl_frame");
     } else {
