@@ -58,6 +58,7 @@ STAGE_BYTES_PER_PX = {
     "ccl_flatten": 1 / 8,
     "ccl_rowscan": 0,
     "ccl_rank": 1 / 8,
+    "ccl_frame": 1 / 8,          # per-frame labelling kernel: bit mask in, one sparse word per run out
     "ccl_paint": 1 / 8 + 4,      # bit mask in, int32 labels out
     "stats_init": 0,
 }
