@@ -245,10 +245,11 @@ def test_morphology_golden_and_oracle(ops, golden, oracle):
 @pytest.fixture(params=["frame-lds", "frame-large", "chip-wide"])
 def ccl_mode(request):
     """the three labelling code paths of launch_ccl (va_ccl.hip), selected through the library's
-    test hooks: one workgroup per frame with the forest in LDS (default), the same kernel's
+    test hooks: one workgroup per frame with the forest in LDS (the default for large batches), the same kernel's
     large-frame mode (forest in the label image; forced by a tiny LDS budget), and the chip-wide
     multi-pass path that frames taller than the LDS row table take"""
-    env = {"frame-lds": {}, "frame-large": {"VA_CCL_LDS_RUNS": "7"},
+    # (without a hook the library picks by batch size: per-frame kernel from 96 frames up)
+    env = {"frame-lds": {"VA_CCL_LDS_RUNS": "1000000"}, "frame-large": {"VA_CCL_LDS_RUNS": "7"},
            "chip-wide": {"VA_CCL_LEGACY": "1"}}[request.param]
     os.environ.update(env)
     yield request.param

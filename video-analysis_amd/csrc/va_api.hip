@@ -672,7 +672,7 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
         PIPE_MALLOC(p->bits[0], bb);
         PIPE_MALLOC(p->bits[1], bb);
         if (cfg->connectivity) {
-            p->ccl_ws_bytes = 2 * align_up(nb * cfg->height * sizeof(int32_t));
+            p->ccl_ws_bytes = ccl_rows_workspace_bytes(cfg->max_batch, cfg->height);
             PIPE_MALLOC(p->ccl_ws, p->ccl_ws_bytes);
             PIPE_MALLOC(p->counts_scratch, align_up(nb * sizeof(int32_t)));
         }
@@ -846,7 +846,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     bool forest_ready = false;
     if (c.morph_count > 0 && morph_fused_supported(c.width, p->se, c.morph_count)) {
         // the chip-wide labelling path wants its forest planted by the last morphology op
-        int32_t *plant = ccl_frame_kernel_used(c.height, c.width) ? nullptr : labels;
+        int32_t *plant = ccl_frame_kernel_used(n, c.height, c.width) ? nullptr : labels;
         rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], plant, n, c.height, c.width, c.morph_op,
                                 p->se, c.morph_count, st);
         if (rc)

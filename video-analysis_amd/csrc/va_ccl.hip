@@ -156,6 +156,35 @@ __device__ __forceinline__ SpanCtx span_ctx(int h, int w32, size_t total_rows)
     return c;
 }
 
+// The chip-wide labelling passes run either over all frames of a batch or over the frames the
+// per-frame kernel handed back (more runs than its LDS table holds): grid = (row blocks of one
+// frame, frame slots), every block loops over the listed frames with stride gridDim.y.
+struct FrameList {
+    const int32_t *list;    // frame indices; nullptr: frames 0 .. n-1
+    const int32_t *count;   // number of listed frames (device memory), unused without a list
+    int n;
+};
+__device__ __forceinline__ int frames_listed(const FrameList &fl) { return fl.list ? *fl.count : fl.n; }
+__device__ __forceinline__ int frame_at(const FrameList &fl, int i) { return fl.list ? fl.list[i] : i; }
+
+__device__ __forceinline__ SpanCtx span_ctx_in_frame(int f, int h, int w32)
+{
+    SpanCtx c;
+    c.lane = threadIdx.x & (kWave - 1);
+    c.f = f;
+    c.y = blockIdx.x * kSparseRowsPerBlock + (int)(threadIdx.x >> 6) * kRowsPerWave +
+          (c.lane & (kRowsPerWave - 1));
+    const int g = c.lane >> 3, G = (w32 + 7) >> 3;
+    c.w0 = g * G;
+    c.w1 = min(w32, c.w0 + G);
+    const bool has_row = c.y < h;
+    c.valid = has_row && c.w0 < c.w1;
+    if (!has_row)
+        c.y = 0;
+    c.row = (size_t)f * h + c.y;
+    return c;
+}
+
 // ---- K1: every run's first pixel becomes a singleton tree ---------------------------------
 // (the *_span functions are the per-lane bodies: the chip-wide kernels below map lanes to rows
 // through blockIdx, the per-frame kernel's large-frame mode loops over its frame's rows)
@@ -178,12 +207,14 @@ __device__ __forceinline__ void init_span(const uint32_t *row, int32_t *L, int y
 
 __global__ void __launch_bounds__(kBlock)
 ccl_init_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
-                int w32, size_t total_rows)
+                int w32, FrameList fl)
 {
-    const SpanCtx c = span_ctx(h, w32, total_rows);
-    if (!c.valid)
-        return;
-    init_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1);
+    const int nf = frames_listed(fl);
+    for (int i = blockIdx.y; i < nf; i += gridDim.y) {
+        const SpanCtx c = span_ctx_in_frame(frame_at(fl, i), h, w32);
+        if (c.valid)
+            init_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1);
+    }
 }
 
 // ---- K2: link runs of row y with runs of row y-1 --------------------------------------------
@@ -236,12 +267,14 @@ __device__ __forceinline__ void link_span(const uint32_t *row, int32_t *L, int y
 template <bool CONN8>
 __global__ void __launch_bounds__(kBlock)
 ccl_link_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
-                int w32, size_t total_rows)
+                int w32, FrameList fl)
 {
-    const SpanCtx c = span_ctx(h, w32, total_rows);
-    if (!c.valid || c.y == 0)
-        return;
-    link_span<CONN8>(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, w32, c.w0, c.w1);
+    const int nf = frames_listed(fl);
+    for (int i = blockIdx.y; i < nf; i += gridDim.y) {
+        const SpanCtx c = span_ctx_in_frame(frame_at(fl, i), h, w32);
+        if (c.valid && c.y > 0)
+            link_span<CONN8>(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, w32, c.w0, c.w1);
+    }
 }
 
 // ---- K3: flatten every run to its root, count roots per row ---------------------------------
@@ -292,24 +325,30 @@ __device__ __forceinline__ int row_prefix(int v, int lane)
 
 __global__ void __launch_bounds__(kBlock)
 ccl_flatten_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
-                   int32_t *__restrict__ row_cnt, int h, int w, int w32, size_t total_rows)
+                   int32_t *__restrict__ row_cnt, int h, int w, int w32, FrameList fl)
 {
-    const SpanCtx c = span_ctx(h, w32, total_rows);
-    int cnt = 0;
-    if (c.valid)
-        cnt = flatten_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1);
-    cnt = row_sum(cnt);
-    if (c.lane < kRowsPerWave && c.row < total_rows)
-        row_cnt[c.row] = cnt;
+    const int nf = frames_listed(fl);
+    for (int i = blockIdx.y; i < nf; i += gridDim.y) {
+        const SpanCtx c = span_ctx_in_frame(frame_at(fl, i), h, w32);
+        int cnt = 0;
+        if (c.valid)
+            cnt = flatten_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1);
+        cnt = row_sum(cnt);
+        const int y = blockIdx.x * kSparseRowsPerBlock + (int)(threadIdx.x >> 6) * kRowsPerWave + c.lane;
+        if (c.lane < kRowsPerWave && y < h)
+            row_cnt[(size_t)c.f * h + y] = cnt;
+    }
 }
 
 // ---- K4: per frame exclusive scan of the row counts ------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 ccl_rowscan_kernel(const int32_t *__restrict__ row_cnt, int32_t *__restrict__ row_off,
-                   int32_t *__restrict__ counts, int h)
+                   int32_t *__restrict__ counts, int h, FrameList fl)
 {
     __shared__ int part[kBlock];
-    const int f = blockIdx.x, t = threadIdx.x;
+    if ((int)blockIdx.x >= frames_listed(fl))
+        return;
+    const int f = frame_at(fl, blockIdx.x), t = threadIdx.x;
     const int32_t *cnt = row_cnt + (size_t)f * h;
     int32_t *off = row_off + (size_t)f * h;
     const int chunk = (h + kBlock - 1) / kBlock;
@@ -378,12 +417,14 @@ __device__ __forceinline__ void rank_span(const uint32_t *row, int32_t *L, int y
 
 __global__ void __launch_bounds__(kBlock)
 ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
-                const int32_t *__restrict__ row_off, int h, int w, int w32, size_t total_rows)
+                const int32_t *__restrict__ row_off, int h, int w, int w32, FrameList fl)
 {
-    const SpanCtx c = span_ctx(h, w32, total_rows);
-    const uint32_t *row = bits + (c.row < total_rows ? c.row : 0) * w32;
-    rank_span(row, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1, c.lane, c.valid,
-              c.valid ? row_off[c.row] : 0);
+    const int nf = frames_listed(fl);
+    for (int i = blockIdx.y; i < nf; i += gridDim.y) {
+        const SpanCtx c = span_ctx_in_frame(frame_at(fl, i), h, w32);
+        rank_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1, c.lane,
+                  c.valid, c.valid ? row_off[c.row] : 0);
+    }
 }
 
 // ---- per-frame labelling: one workgroup owns one frame, forest in LDS ------------------------
@@ -404,14 +445,17 @@ ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
 //     and one sparse write per run: -(label) at the run's first pixel (bit 30 set for runs that
 //     are not their component's first), which is what ccl_paint_kernel / the contour tracer read.
 // Frames with more runs than the LDS table holds (noise, checkerboards) are labelled by the
-// same workgroup with the forest in the label image (the *_span bodies above): same result,
-// one CU per frame.
+// same workgroup with the forest in the label image (the *_span bodies above): same result, but
+// one CU per frame -- a bounded slow path for pathological masks (handing such frames back to
+// the chip-wide passes was measured: five near-empty launches cost every batch 4 %).
 constexpr int kFrameThreads = 1024;
 constexpr int kFrameWaves = kFrameThreads / kWave;                // 16
 constexpr int kFrameRowsPerIter = kFrameWaves * kRowsPerWave;     // 128 rows per sweep step
 constexpr int kFrameLdsWords = 37 * 1024;                         // 148 KB, partitioned per launch
 constexpr int kQueue = 128;                                       // queued pairs per wave
 constexpr int kMinLdsRuns = 4096;                                 // else: chip-wide path
+constexpr int kMinFramesForFrameKernel = 96;                      // batches below: chip-wide path
+constexpr int kMaxFrameWords = 80 * 1024;                         // mask words per frame (1080p: 64.8 k)
 constexpr int kNonRootBit = 1 << 30;
 
 constexpr int kChunk = 8;                                         // words per lane and chunk
@@ -1239,23 +1283,38 @@ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_
 }  // namespace
 
 // the per-frame LDS kernel takes frames whose row table and row stages leave room for at least
-// kMinLdsRuns runs; VA_CCL_LEGACY=1 (test hook) forces the chip-wide multi-pass path
-bool ccl_frame_kernel_used(int h, int w)
+// kMinLdsRuns runs, in batches of at least kMinFramesForFrameKernel frames; VA_CCL_LEGACY=1 (test
+// hook) forces the chip-wide multi-pass path, VA_CCL_LDS_RUNS=n the per-frame kernel with a small table
+// (its large-frame mode) whatever the batch size
+bool ccl_frame_kernel_used(int n, int h, int w)
 {
     const char *e = getenv("VA_CCL_LEGACY");
     if (e && atoi(e) != 0)
         return false;
+    // one CU per frame pays off from about a third of the chip's CUs; smaller batches are
+    // spread over all CUs by the chip-wide passes
+    if (n < kMinFramesForFrameKernel && !getenv("VA_CCL_LDS_RUNS"))
+        return false;
     const int w32 = words_per_row(w);
+    // larger frames (4K) overflow the run table too often and leave CUs idle: chip-wide passes
+    if ((long long)h * w32 > kMaxFrameWords)
+        return false;
     return span_chunks(w32) <= 2 && frame_layout(h, w32).lds_runs >= kMinLdsRuns;
+}
+
+// [row_cnt][row_off]
+size_t ccl_rows_workspace_bytes(int n, int h)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return 2 * up((size_t)n * h * sizeof(int32_t));
 }
 
 size_t ccl_workspace_bytes(int n, int h, int w)
 {
-    // [bit mask for the u8 entry point][row_cnt][row_off]
+    // [bit mask for the u8 entry point][rows workspace]
     size_t bits = (size_t)n * h * words_per_row(w) * sizeof(uint32_t);
-    size_t rows = (size_t)n * h * sizeof(int32_t);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    return up(bits) + 2 * up(rows);
+    return up(bits) + ccl_rows_workspace_bytes(n, h);
 }
 
 // workspace here = row_cnt + row_off only (the caller owns the bit mask)
@@ -1277,17 +1336,40 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     const int w32 = words_per_row(w);
     const size_t total_rows = (size_t)n * h;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    VA_REQUIRE(ws_bytes >= 2 * up(total_rows * sizeof(int32_t)), "label: workspace too small");
+    VA_REQUIRE(ws_bytes >= ccl_rows_workspace_bytes(n, h), "label: workspace too small");
     int32_t *row_cnt = (int32_t *)workspace;
     int32_t *row_off = (int32_t *)((char *)workspace + up(total_rows * sizeof(int32_t)));
     const int grid = cdiv((long long)total_rows, kRowsPerBlock);          // paint: wave = row
-    const int sgrid = cdiv((long long)total_rows, kSparseRowsPerBlock);   // sparse: wave = 8 rows
 
-    if (ccl_frame_kernel_used(h, w)) {
-        // one workgroup per frame, forest in LDS (falls back to the label image inside the kernel
-        // for frames with more runs than the table holds)
+    const dim3 sgrid_all((unsigned)cdiv(h, kSparseRowsPerBlock), (unsigned)min(n, 4096));
+    FrameList all{nullptr, nullptr, n};
+    auto chip_wide = [&](const dim3 &sgrid, const FrameList &fl, int nscan, bool init) -> int {
+        if (init) {
+            ccl_init_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, fl);
+            VA_LAUNCH_CHECK("ccl_init_kernel");
+            VA_MARK("ccl_init");
+        }
+        if (connectivity == 8)
+            ccl_link_kernel<true><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, fl);
+        else
+            ccl_link_kernel<false><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, fl);
+        VA_LAUNCH_CHECK("ccl_link_kernel");
+        VA_MARK("ccl_link");
+        ccl_flatten_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_cnt, h, w, w32, fl);
+        VA_LAUNCH_CHECK("ccl_flatten_kernel");
+        VA_MARK("ccl_flatten");
+        ccl_rowscan_kernel<<<nscan, kBlock, 0, st>>>(row_cnt, row_off, counts, h, fl);
+        VA_LAUNCH_CHECK("ccl_rowscan_kernel");
+        VA_MARK("ccl_rowscan");
+        ccl_rank_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, fl);
+        VA_LAUNCH_CHECK("ccl_rank_kernel");
+        VA_MARK("ccl_rank");
+        return VA_OK;
+    };
+    if (ccl_frame_kernel_used(n, h, w)) {
+        // one workgroup per frame, forest in LDS
         FrameLayout lay = frame_layout(h, w32);
-        if (const char *e = getenv("VA_CCL_LDS_RUNS"))    // test hook: force the large-frame mode
+        if (const char *e = getenv("VA_CCL_LDS_RUNS"))    // test hook: force the hand-back
             lay.lds_runs = max(0, min(lay.lds_runs, atoi(e)));
         const int vec = (w32 % 4 == 0) && aligned(bits, 16);
 #define VA_FRAME_LAUNCH(C8, NCH) \
@@ -1307,26 +1389,9 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
         VA_LAUNCH_CHECK("ccl_frame_kernel");
         VA_MARK("ccl_frame");
     } else {
-        if (!forest_ready) {
-            ccl_init_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
-            VA_LAUNCH_CHECK("ccl_init_kernel");
-            VA_MARK("ccl_init");
-        }
-        if (connectivity == 8)
-            ccl_link_kernel<true><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
-        else
-            ccl_link_kernel<false><<<sgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows);
-        VA_LAUNCH_CHECK("ccl_link_kernel");
-        VA_MARK("ccl_link");
-        ccl_flatten_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_cnt, h, w, w32, total_rows);
-        VA_LAUNCH_CHECK("ccl_flatten_kernel");
-        VA_MARK("ccl_flatten");
-        ccl_rowscan_kernel<<<n, kBlock, 0, st>>>(row_cnt, row_off, counts, h);
-        VA_LAUNCH_CHECK("ccl_rowscan_kernel");
-        VA_MARK("ccl_rowscan");
-        ccl_rank_kernel<<<sgrid, kBlock, 0, st>>>(bits, labels, row_off, h, w, w32, total_rows);
-        VA_LAUNCH_CHECK("ccl_rank_kernel");
-        VA_MARK("ccl_rank");
+        int rc = chip_wide(sgrid_all, all, n, !forest_ready);
+        if (rc)
+            return rc;
     }
     if (!paint)
         return VA_OK;
