@@ -491,6 +491,120 @@ morph_stream_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst
     }
 }
 
+// The same chains without forest planting (the per-frame labelling kernel needs none): one load per
+// row and lane -- the left/right words come from the neighbouring lanes by DPP wave shifts -- and
+// eight rows of loads in flight (a row-by-row march pays one memory round trip per row).
+constexpr int kStreamGroup = 8;
+
+__device__ __forceinline__ uint32_t lane_left(uint32_t v)    // value of lane - 1 (0 into lane 0)
+{
+    return __builtin_amdgcn_update_dpp(0u, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t lane_right(uint32_t v)   // value of lane + 1 (0 into lane 63)
+{
+    return __builtin_amdgcn_update_dpp(0u, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+
+template <int K0, int K1>
+__global__ void __launch_bounds__(kBlock)
+morph_stream2_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int n, int h, int w,
+                     int w32, int nbands, int nchunks, uint32_t flip_in, uint32_t flip_mid,
+                     uint32_t flip_out)
+{
+    constexpr int A0 = K0 / 2, A1 = K1 / 2;
+    // lanes [LO, LO+COLS) store; the others only supply neighbour words (two per side for two ops)
+    constexpr int LO = K1 ? 2 : 1;
+    constexpr int COLS = K1 ? 60 : 62;
+    const int lane = threadIdx.x & 63;
+    size_t item = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // (frame, band, chunk)
+    const int chunk = (int)(item % nchunks);
+    item /= nchunks;
+    const int band = (int)(item % nbands);
+    const size_t f = item / nbands;
+    if (f >= (size_t)n)
+        return;   // surplus waves of the last block (wave-uniform)
+    const int wi = chunk * COLS + lane - LO;             // this lane's word column
+    const bool col_in = wi >= 0 && wi < w32;
+    const bool col_store = col_in && lane >= LO && lane < LO + COLS;
+    const int tail = w & 31;
+    const uint32_t valid = !col_in ? 0u : (wi == w32 - 1 && tail ? (0xFFFFFFFFu >> (32 - tail)) : 0xFFFFFFFFu);
+    const uint32_t *fsrc = src + f * (size_t)h * w32 + min(max(wi, 0), w32 - 1);
+    uint32_t *fdst = dst + f * (size_t)h * w32;
+
+    const int y0 = band * kStreamBand;
+    if (y0 >= h)
+        return;
+    const int y_first = y0 - A0 - A1;                       // first input row marched
+    const int y_last = min(h, y0 + kStreamBand) - 1 + A0 + A1;
+
+    // rows y .. y+7: unconditional loads from clamped rows, masked afterwards
+    auto load_group = [&](int y, uint32_t (&g)[kStreamGroup]) {
+#pragma unroll
+        for (int k = 0; k < kStreamGroup; k++)
+            g[k] = fsrc[(size_t)min(max(y + k, 0), h - 1) * w32];
+#pragma unroll
+        for (int k = 0; k < kStreamGroup; k++)
+            g[k] = (y + k >= 0 && y + k < h) ? ((g[k] ^ flip_in) & valid) : 0u;
+    };
+
+    uint32_t win0[K0], win1[K1 ? K1 : 1];
+#pragma unroll
+    for (int k = 0; k < K0; k++)
+        win0[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < (K1 ? K1 : 1); k++)
+        win1[k] = 0u;
+
+    uint32_t cur[kStreamGroup], nxt[kStreamGroup];
+    load_group(y_first, nxt);
+    for (int yg = y_first; yg <= y_last; yg += kStreamGroup) {
+#pragma unroll
+        for (int k = 0; k < kStreamGroup; k++)
+            cur[k] = nxt[k];
+        if (yg + kStreamGroup <= y_last)
+            load_group(yg + kStreamGroup, nxt);    // the next eight rows fly behind this group's ALU work
+#pragma unroll
+        for (int k = 0; k < kStreamGroup; k++) {
+            const int y = yg + k;
+            if (y > y_last)
+                break;
+            const uint32_t c = cur[k], l = lane_left(c), r = lane_right(c);
+            // ---- op 0: horizontal pass of input row y, vertical window -> row y - A0
+#pragma unroll
+            for (int j = 0; j + 1 < K0; j++)
+                win0[j] = win0[j + 1];
+            win0[K0 - 1] = hdilate<K0>(l, c, r);
+            uint32_t v0 = 0u;
+#pragma unroll
+            for (int j = 0; j < K0; j++)
+                v0 |= win0[j];
+            const int ya = y - A0;                    // row of v0
+            uint32_t out;
+            int yo;
+            if constexpr (K1 == 0) {
+                out = (v0 ^ flip_out) & valid;
+                yo = ya;
+            } else {
+                // input of op 1: rows outside the frame contribute nothing
+                const uint32_t t = (ya >= 0 && ya < h) ? ((v0 ^ flip_mid) & valid) : 0u;
+                const uint32_t tl = lane_left(t), tr = lane_right(t);
+#pragma unroll
+                for (int j = 0; j + 1 < K1; j++)
+                    win1[j] = win1[j + 1];
+                win1[K1 ? K1 - 1 : 0] = hdilate<(K1 ? K1 : 1)>(tl, t, tr);
+                uint32_t v1 = 0u;
+#pragma unroll
+                for (int j = 0; j < K1; j++)
+                    v1 |= win1[j];
+                out = (v1 ^ flip_out) & valid;
+                yo = ya - A1;
+            }
+            if (col_store && yo >= y0 && yo < y0 + kStreamBand && yo < h)
+                fdst[(size_t)yo * w32 + wi] = out;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ morphology on u8 images
 template <bool DILATE>
 __global__ void __launch_bounds__(kBlock)
@@ -597,7 +711,7 @@ static int launch_stream(const uint32_t *src, uint32_t *dst, int32_t *labels_ini
                          int w, const int *ops, hipStream_t st)
 {
     const int w32 = words_per_row(w);
-    const int cols = K1 ? 60 : 63;
+    const int cols = K1 ? 60 : (labels_init ? 63 : 62);
     const int nchunks = cdiv(w32, cols), nbands = cdiv(h, kStreamBand);
     const size_t items = (size_t)n * nbands * nchunks;
     // erode = complement . dilate . complement; adjacent complements cancel
@@ -607,8 +721,12 @@ static int launch_stream(const uint32_t *src, uint32_t *dst, int32_t *labels_ini
     // the grid is rounded up to whole blocks: surplus waves see y0 >= h via the band index
     const int waves_per_block = kBlock / 64;
     const size_t blocks = (items + waves_per_block - 1) / waves_per_block;
-    morph_stream_kernel<K0, K1><<<(unsigned)blocks, kBlock, 0, st>>>(
-        src, dst, labels_init, n, h, w, w32, nbands, nchunks, flip_in, flip_mid, flip_out);
+    if (labels_init)
+        morph_stream_kernel<K0, K1><<<(unsigned)blocks, kBlock, 0, st>>>(
+            src, dst, labels_init, n, h, w, w32, nbands, nchunks, flip_in, flip_mid, flip_out);
+    else
+        morph_stream2_kernel<K0, K1><<<(unsigned)blocks, kBlock, 0, st>>>(
+            src, dst, n, h, w, w32, nbands, nchunks, flip_in, flip_mid, flip_out);
     VA_LAUNCH_CHECK("morph_stream_kernel");
     return VA_OK;
 }
