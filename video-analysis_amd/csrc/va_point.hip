@@ -114,29 +114,48 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
     for (int k = 0; k < V; k++)
         m[k] = mean[i0 + k];
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-    // frames and differences are one-touch streams: non-temporal loads/stores keep them out of L2
-    v2u cur = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(frames + i0));
-    for (int f = 0; f < n; f++) {
-        v2u nxt = cur;
-        if (f + 1 < n)   // prefetch the next frame's pixels behind this frame's arithmetic
-            nxt = __builtin_nontemporal_load(
-                reinterpret_cast<const v2u *>(frames + (size_t)(f + 1) * px + i0));
-        uint8_t p[V], o[V];
-        memcpy(p, &cur, 8);
-        const double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
-        const double y = recip[f];
+    // frames and differences are one-touch streams: non-temporal loads/stores keep them out of L2.
+    // Frames are walked in groups of kAhead: the next group's loads are issued before this
+    // group's arithmetic (only ~4 waves per SIMD exist: 8 px per thread), so a load has kAhead
+    // frame steps to arrive.
+    constexpr int kAhead = 4;
+    const uint8_t *src = frames + i0;
+    v2u cur[kAhead], nxt[kAhead];
 #pragma unroll
-        for (int k = 0; k < V; k++) {
-            const double fr = (double)p[k];
-            o[k] = sat_u8_trunc(fabs(fr - m[k]));
-            m[k] = div_by_uniform(m[k] * dn, dn1, y) + div_by_uniform(fr, dn1, y);
+    for (int j = 0; j < kAhead; j++)
+        nxt[j] = __builtin_nontemporal_load(
+            reinterpret_cast<const v2u *>(src + (size_t)min(j, n - 1) * px));
+    for (int f0 = 0; f0 < n; f0 += kAhead) {
+#pragma unroll
+        for (int j = 0; j < kAhead; j++)
+            cur[j] = nxt[j];
+        if (f0 + kAhead < n) {
+#pragma unroll
+            for (int j = 0; j < kAhead; j++)
+                nxt[j] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(
+                    src + (size_t)min(f0 + kAhead + j, n - 1) * px));
         }
-        if (diff) {
-            v2u v;
-            memcpy(&v, o, 8);
-            __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(diff + (size_t)f * px + i0));
+#pragma unroll
+        for (int j = 0; j < kAhead; j++) {
+            const int f = f0 + j;
+            if (f >= n)
+                break;
+            uint8_t p[V], o[V];
+            memcpy(p, &cur[j], 8);
+            const double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
+            const double y = recip[f];
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const double fr = (double)p[k];
+                o[k] = sat_u8_trunc(fabs(fr - m[k]));
+                m[k] = div_by_uniform(m[k] * dn, dn1, y) + div_by_uniform(fr, dn1, y);
+            }
+            if (diff) {
+                v2u v;
+                memcpy(&v, o, 8);
+                __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(diff + (size_t)f * px + i0));
+            }
         }
-        cur = nxt;
     }
 #pragma unroll
     for (int k = 0; k < V; k++)
