@@ -53,6 +53,9 @@ constexpr int kLdsStride = kTileCols + 32 + 16;   // staged row: strip + halo + 
                                                   // -> ds_read_b128 of 32 rows is conflict free
 static_assert((kLdsStride / 16) % 2 == 1, "LDS row stride must be an odd multiple of 16 bytes");
 constexpr int kTapTable = 128;     // zero-padded tap table, tap i at [48 + i]
+constexpr int kFlushTiles = 8;     // mask words are written out every 8 output tiles
+constexpr int kFlushRows = 32 * kFlushTiles;
+static_assert(kFlushRows == kWaves * 64, "one thread per collected row at a flush");
 
 struct MfmaTaps {
     int ksize;
@@ -72,6 +75,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[2][32 * kLdsStride];
     __shared__ int8_t s_taps[kTapTable];
+    // outputs are collected in LDS and leave as 16-byte pieces: four-byte stores scattered over 32
+    // rows per instruction cost this kernel 30 % (measured), although they add no HBM bytes
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[2][kFlushRows][kWaves];        // HAS_BITS
+    __shared__ __attribute__((aligned(16))) uint8_t s_dst[HAS_DST ? 2 : 1][HAS_DST ? 32 : 1][kTileCols];
 
     // ---- start-up: zero-padded tap table in LDS (the only workgroup-wide step) -------------
     if (threadIdx.x < kTapTable) {
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
         return;
     const bool active = strip < nstrips;                 // waves right of the frame only load
 
+    const int xb = (q % blocks_per_frame) * kTileCols;   // first column of the workgroup's strip
     const int R = tp.ksize >> 1;
     const int nn = lane & 31, hh = lane >> 5;
     const int x0 = strip * 32;
@@ -129,7 +137,6 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
     const int k_dst = acc_min - 1 + 32768;   // (acc + 2^15) = k_dst - t
 
     const uint8_t *fsrc = src + (size_t)frame * h * w;
-    const int xb = (q % blocks_per_frame) * kTileCols;   // first column of the workgroup's strip
     const int ntiles = (h + 31) >> 5;                    // output tiles; row tiles 0..ntiles
 
     // ---- cooperative loads: 32 rows x 10 chunks of 16 B.  load A: thread -> (row tid/8, chunk
@@ -189,9 +196,15 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
         c_init[i] = c_lo;
     asm volatile("" : "+v"(c_init));
 
-    uint32_t *brow_ptr = bits + ((size_t)frame * h + nn) * w32 + strip;   // HAS_BITS
-    uint8_t *drow_ptr = dst + ((size_t)frame * h + nn) * w + x0 + 4 * hh; // HAS_DST
-    const int valid = min(32, w - x0);
+    // Outputs go through buffer stores (a lane that must not store gets an out-of-range offset,
+    // which the hardware drops: no branch, so the waits can count the stores in flight).
+    const uint32_t kOob = 0xFFFFFFFFu;
+    __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        HAS_BITS ? (void *)(bits + (size_t)frame * h * w32) : nullptr, 0, h * w32 * 4, 0x00027000);
+    __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        HAS_DST ? (void *)(dst + (size_t)frame * h * w) : nullptr, 0, h * w, 0x00027000);
+    const int xbw = xb >> 5;                              // first mask word of the workgroup's strip
+    const int valid = max(0, min(32, w - x0));
     const uint32_t colmask = valid < 32 ? (1u << valid) - 1u : ~0u;
     const int frag_off = nn * kLdsStride + 32 * wave + 16 * hh;           // this lane's A bytes
 
@@ -222,8 +235,6 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
         // ---- epilogue of output tile t-2: lane = output row nn (+ half hh), register i = column
         //      (i&3) + 8 (i>>2) + 4 hh ---------------------------------------------------------------
         {
-            const int y = 32 * (t - 2) + nn;
-            const bool row_ok = active && (unsigned)y < (unsigned)h;
             uint32_t p = 0;
             int tv[16];
 #pragma unroll
@@ -232,19 +243,16 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
                 if (HAS_BITS)
                     p = __builtin_amdgcn_alignbit(p, (uint32_t)tv[i], 31);
             }
+            const int u = t - 2;                               // output tile of this epilogue
             if (HAS_DST) {
-                if (row_ok) {
-                    uint8_t *drow = drow_ptr + (ptrdiff_t)(t - 2) * 32 * w;
 #pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const uint32_t b0 = (uint32_t)(k_dst - tv[4 * g]) >> 16;
-                        const uint32_t b1 = (uint32_t)(k_dst - tv[4 * g + 1]) >> 16;
-                        const uint32_t b2 = (uint32_t)(k_dst - tv[4 * g + 2]) >> 16;
-                        const uint32_t b3 = (uint32_t)(k_dst - tv[4 * g + 3]) >> 16;
-                        if (x0 + 8 * g + 4 * hh < w)
-                            *reinterpret_cast<uint32_t *>(drow + 8 * g) =
-                                b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-                    }
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t b0 = (uint32_t)(k_dst - tv[4 * g]) >> 16;
+                    const uint32_t b1 = (uint32_t)(k_dst - tv[4 * g + 1]) >> 16;
+                    const uint32_t b2 = (uint32_t)(k_dst - tv[4 * g + 2]) >> 16;
+                    const uint32_t b3 = (uint32_t)(k_dst - tv[4 * g + 3]) >> 16;
+                    *reinterpret_cast<uint32_t *>(&s_dst[u & 1][nn][32 * wave + 8 * g + 4 * hh]) =
+                        b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
                 }
             }
             if (HAS_BITS) {
@@ -252,8 +260,9 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
                 wd <<= 4 * hh;
                 // lanes 0..31 receive the word of lane + 32 (v_permlane32_swap, no LDS trip)
                 const auto sw = __builtin_amdgcn_permlane32_swap(wd, wd, false, false);
-                if (hh == 0 && row_ok)
-                    brow_ptr[(ptrdiff_t)(t - 2) * 32 * w32] = (wd | sw[1]) & colmask;
+                if (hh == 0 && u >= 0)
+                    s_bits[(u / kFlushTiles) & 1][(u % kFlushTiles) * 32 + nn][wave] =
+                        active ? (wd | sw[1]) & colmask : 0u;
             }
         }
 
@@ -280,6 +289,30 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
         prev_hi = cur_hi;
         prev_lo = cur_lo;
         __syncthreads();
+
+        // ---- what the epilogues collected leaves as 16-byte pieces (other buffer than the next
+        //      epilogue writes) ----------------------------------------------------------------------
+        const int u = t - 2;
+        if (HAS_DST && u >= 0) {
+            const int r = tid >> 3, c16 = (tid & 7) * 16, y = 32 * u + r;
+            const bool ok = y < h && xb + c16 < w;                       // w % 16 == 0
+            const v4i v = *reinterpret_cast<const v4i *>(&s_dst[u & 1][r][c16]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, dst_rsrc, ok ? (uint32_t)(y * w + xb + c16) : kOob, 0, 0);
+        }
+        if (HAS_BITS && u >= 0 && (u % kFlushTiles == kFlushTiles - 1 || u == ntiles - 1)) {
+            const int g = u / kFlushTiles, y = g * kFlushRows + tid;
+            const bool ok = y < h && tid < (u % kFlushTiles + 1) * 32;
+            const v4i v = *reinterpret_cast<const v4i *>(&s_bits[g & 1][tid][0]);
+            const uint32_t off = (uint32_t)(y * w32 + xbw) * 4u;
+            if (xbw + kWaves <= w32) {                                   // whole strip inside the row
+                __builtin_amdgcn_raw_buffer_store_b128(v, bits_rsrc, ok ? off : kOob, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kWaves; k++)
+                    __builtin_amdgcn_raw_buffer_store_b32(v[k], bits_rsrc,
+                                                          ok && xbw + k < w32 ? off + 4 * k : kOob, 0, 0);
+            }
+        }
     }
 }
 
