@@ -323,6 +323,21 @@ __device__ __forceinline__ int row_prefix(int v, int lane)
     return incl - v;
 }
 
+// exclusive prefix over the 64 lanes of the wave (DPP: Hillis-Steele inside the rows of 16, then
+// the two row broadcasts); *total = sum over the wave
+__device__ __forceinline__ int wave_prefix(int v, int *total)
+{
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    *total = __builtin_amdgcn_readlane(x, 63);
+    return x - v;
+}
+
 __global__ void __launch_bounds__(kBlock)
 ccl_flatten_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
                    int32_t *__restrict__ row_cnt, int h, int w, int w32, FrameList fl)
@@ -632,7 +647,6 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
 {
     __shared__ __attribute__((aligned(16))) int s_mem[kFrameLdsWords];
     __shared__ int s_part[kFrameWaves];
-    __shared__ int s_qcnt[kFrameWaves];
     __shared__ int s_total;
 
     const int f = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & (kWave - 1);
@@ -646,48 +660,56 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     int *rowbase = s_mem + lay.rowbase_off;
     int *parent = s_mem + lay.parent_off;
     const int sweeps = (h + kFrameRowsPerIter - 1) / kFrameRowsPerIter;
-    if (lane == 0)
-        s_qcnt[wv] = 0;
 
     // stage image rows y0 - 1 ... y0 + 7 of this wave's sweep step (slot 0 is the row above y0).
     // All nine loads are issued before any is used -- one memory round trip per sweep step --
     // from clamped, always valid addresses: slots of rows outside the frame hold a copy of an
     // edge row, and no lane that reads them is `valid`.
     typedef int v4i __attribute__((ext_vector_type(4)));
-    auto stage_rows = [&](int y0) {
+    struct RowRegs {
+        v4i v[kRowsPerWave + 1];   // 16 bytes of each row (vec) or words lane, lane + 64 in .x, .y
+    };
+    auto issue_rows = [&](int y0, RowRegs &rr) {
         if (vec) {
             const int col = min(lane * 4, w32 - 4);
-            v4i t[kRowsPerWave + 1];
 #pragma unroll
             for (int j = 0; j <= kRowsPerWave; j++) {
                 const int y = min(max(y0 - 1 + j, 0), h - 1);
-                t[j] = *reinterpret_cast<const v4i *>(fbits + (size_t)y * w32 + col);
-            }
-            wave_sync();                                // earlier readers of the stage are done
-            if (lane * 4 < w32) {
-#pragma unroll
-                for (int j = 0; j <= kRowsPerWave; j++)
-                    *reinterpret_cast<v4i *>(stage + j * rs + lane * 4) = t[j];
+                rr.v[j] = *reinterpret_cast<const v4i *>(fbits + (size_t)y * w32 + col);
             }
         } else {
             const int c0 = min(lane, w32 - 1), c1 = min(lane + kWave, w32 - 1);   // w32 <= 128
-            int t0[kRowsPerWave + 1], t1[kRowsPerWave + 1];
 #pragma unroll
             for (int j = 0; j <= kRowsPerWave; j++) {
                 const uint32_t *src = fbits + (size_t)min(max(y0 - 1 + j, 0), h - 1) * w32;
-                t0[j] = (int)src[c0];
-                t1[j] = (int)src[c1];
+                rr.v[j].x = (int)src[c0];
+                rr.v[j].y = (int)src[c1];
             }
-            wave_sync();
+        }
+    };
+    auto commit_rows = [&](const RowRegs &rr) {
+        wave_sync();                                    // earlier readers of the stage are done
+        if (vec) {
+            if (lane * 4 < w32) {
+#pragma unroll
+                for (int j = 0; j <= kRowsPerWave; j++)
+                    *reinterpret_cast<v4i *>(stage + j * rs + lane * 4) = rr.v[j];
+            }
+        } else {
 #pragma unroll
             for (int j = 0; j <= kRowsPerWave; j++) {
                 if (lane < w32)
-                    stage[j * rs + lane] = t0[j];
+                    stage[j * rs + lane] = rr.v[j].x;
                 if (lane + kWave < w32)
-                    stage[j * rs + lane + kWave] = t1[j];
+                    stage[j * rs + lane + kWave] = rr.v[j].y;
             }
         }
         wave_sync();
+    };
+    auto stage_rows = [&](int y0) {
+        RowRegs rr;
+        issue_rows(y0, rr);
+        commit_rows(rr);
     };
 
     // ---- 1. runs per row, exclusive scan -> first run id of every row -----------------------
@@ -746,9 +768,11 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         parent[i] = i;
     __syncthreads();
 
-    // a pair for the wave's queue; when the queue is full the caller acts on it at once
-    auto push = [&](int a, int b) -> bool {
-        const int slot = atomicAdd(&s_qcnt[wv], 1);
+    // The wave's queue of pairs: every lane counts what it will queue, a wave scan hands out the
+    // slots, then the lanes write their pairs with plain LDS stores (an atomic per pair would
+    // put a dependent LDS round trip into every loop iteration).  Pairs past the queue's end are
+    // acted on at once by the caller.
+    auto put = [&](int slot, int a, int b) -> bool {
         if (slot >= kQueue)
             return false;
         queue[2 * slot] = a;
@@ -769,6 +793,26 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         const int nu = act ? count_starts<NCH>(uw) : 0;
         // runs of the row that start left of this lane's span
         int cc = row_prefix(nc, lane), cu = row_prefix(nu, lane);
+        // contacts of this lane's span (the same bit tricks as below, counted)
+        int ncontacts = 0;
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < NCH; j++)
+#pragma unroll
+                for (int k = 0; k < kChunk; k++) {
+                    const uint32_t mp = mw[j][k], m = mw[j][k + 1], upv = uw[j][k], u = uw[j][k + 1];
+                    const uint32_t v = m & u;
+                    ncontacts += __popc(v & ~((v << 1) | ((mp & upv) >> 31)));
+                    if (CONN8) {
+                        const uint32_t mn = mw[j][k + 2], un = uw[j][k + 2];
+                        const uint32_t uR = (u >> 1) | (un << 31), mR = (m >> 1) | (mn << 31);
+                        const uint32_t uL = (u << 1) | (upv >> 31), mL = (m << 1) | (mp >> 31);
+                        ncontacts += __popc(m & uR & ~u & ~mR) + __popc(m & uL & ~u & ~mL);
+                    }
+                }
+        }
+        int nq_total;
+        int slot = wave_prefix(ncontacts, &nq_total);
         if (act) {
             cc += rowbase[c.y] - 1;        // id of the run that holds pixel x = cc + starts in the
             cu += rowbase[c.y - 1] - 1;    // span at or left of x (same for the row above)
@@ -785,7 +829,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                         const int b = __ffs(vs) - 1;
                         vs &= vs - 1;
                         const int ia = cc + __popc(sc & upto(b)), ib = cu + __popc(su & upto(b));
-                        if (!push(ia, ib))
+                        if (!put(slot++, ia, ib))
                             lds_unite(parent, ia, ib);
                     }
                     if (CONN8) {
@@ -798,7 +842,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                             const int b = __ffs(dr) - 1;
                             dr &= dr - 1;
                             const int ia = cc + __popc(sc & upto(b)), ib = cu + __popc(su & upto(b)) + 1;
-                            if (!push(ia, ib))
+                            if (!put(slot++, ia, ib))
                                 lds_unite(parent, ia, ib);
                         }
                         // (y,x) ~ (y-1,x-1), needed only if neither (y-1,x) nor (y,x-1) is set: no
@@ -809,7 +853,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                             const int b = __ffs(dl) - 1;
                             dl &= dl - 1;
                             const int ia = cc + __popc(sc & upto(b)), ib = cu + __popc(su & upto(b));
-                            if (!push(ia, ib))
+                            if (!put(slot++, ia, ib))
                                 lds_unite(parent, ia, ib);
                         }
                     }
@@ -820,12 +864,9 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         }
         // drain: every lane takes queued contacts, so the wave runs one union chain deep
         wave_sync();
-        const int nq = min(lds_ld(&s_qcnt[wv]), kQueue);
+        const int nq = min(nq_total, kQueue);
         for (int i = lane; i < nq; i += kWave)
             lds_unite(parent, queue[2 * i], queue[2 * i + 1]);
-        wave_sync();
-        if (lane == 0)
-            lds_st(&s_qcnt[wv], 0);
     }
     __syncthreads();
 
@@ -850,20 +891,29 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     __syncthreads();
 
     // ---- 5. one sparse write per run: what the paint pass and the contour tracer read ---------------
-    auto emit = [&](int pix, int id) {
+    // The next sweep step's row loads are issued BEFORE this step's stores, and the stores are
+    // branch-free buffer stores (out-of-range offset = dropped): vmcnt retires in order, so loads
+    // issued after a store would wait for the store's (slow) acknowledgement every step.
+    __amdgpu_buffer_rsrc_t lab_rsrc = __builtin_amdgcn_make_buffer_rsrc(L, 0, h * w * 4, 0x00027000);
+    auto label_of = [&](int id) {
         int v = parent[id];
         if (v >= 0)
             v = -((-parent[v]) | kNonRootBit);
-        L[pix] = v;
+        return v;
     };
+    RowRegs rr;
+    issue_rows(wv * kRowsPerWave, rr);
     for (int it = 0; it < sweeps; it++) {
         const int y0 = it * kFrameRowsPerIter + wv * kRowsPerWave;
-        stage_rows(y0);
+        commit_rows(rr);
+        issue_rows(y0 + kFrameRowsPerIter, rr);         // clamped rows past the frame: harmless
         const FrameSpan c = frame_span<NCH>(y0, h, w32);
         uint32_t mw[NCH][kChunk + 2];
         load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
         const int nc = c.valid ? count_starts<NCH>(mw) : 0;
         int id = row_prefix(nc, lane);
+        int nq_total;
+        int slot = wave_prefix(nc, &nq_total);
         if (c.valid) {
             id += rowbase[c.y];
             const int base = c.y * w + (c.w0 << 5);
@@ -876,20 +926,26 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                         const int b = __ffs(sc) - 1;
                         sc &= sc - 1;
                         const int pix = base + ((j * kChunk + k) << 5) + b;
-                        if (!push(pix, id))
-                            emit(pix, id);
+                        if (!put(slot++, pix, id))
+                            L[pix] = label_of(id);
                         id++;
                     }
                 }
             }
         }
         wave_sync();
-        const int nq = min(lds_ld(&s_qcnt[wv]), kQueue);
-        for (int i = lane; i < nq; i += kWave)
-            emit(queue[2 * i], queue[2 * i + 1]);
-        wave_sync();
-        if (lane == 0)
-            lds_st(&s_qcnt[wv], 0);
+        const int nq = min(nq_total, kQueue);
+#pragma unroll
+        for (int r = 0; r < kQueue / kWave; r++) {
+            const int i = lane + r * kWave;
+            const bool ok = i < nq;
+            int pix = 0, v = 0;
+            if (ok) {
+                pix = queue[2 * i];
+                v = label_of(queue[2 * i + 1]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(v, lab_rsrc, ok ? (uint32_t)pix * 4u : 0xFFFFFFFFu, 0, 0);
+        }
     }
 }
 
