@@ -249,12 +249,11 @@ def ccl_mode(request):
     large-frame mode (forest in the label image; forced by a tiny LDS budget), and the chip-wide
     multi-pass path that frames taller than the LDS row table take"""
     # (without a hook the library picks by batch size: per-frame kernel from 96 frames up)
-    env = {"frame-lds": {"VA_CCL_LDS_RUNS": "1000000"}, "frame-large": {"VA_CCL_LDS_RUNS": "7"},
-           "chip-wide": {"VA_CCL_LEGACY": "1"}}[request.param]
-    os.environ.update(env)
+    path, lds_runs = {"frame-lds": (2, 0), "frame-large": (2, 7), "chip-wide": (1, 0)}[request.param]
+    from video import _hip
+    _hip.check(_hip.lib().va_test_hook_labelling(path, lds_runs))
     yield request.param
-    for k in env:
-        del os.environ[k]
+    _hip.check(_hip.lib().va_test_hook_labelling(0, 0))
 
 
 def test_label_golden_scipy_vectors(ops, golden, ccl_mode):

@@ -306,6 +306,14 @@ int va_gaussian_u8_valu(const uint8_t *src, uint8_t *dst, int n, int h, int w, i
     return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
 }
 
+// test hook: pin the labelling code path of every later call in this process
+int va_test_hook_labelling(int path, int lds_runs)
+{
+    VA_REQUIRE(path >= 0 && path <= 2 && lds_runs >= 0, "va_test_hook_labelling: bad arguments");
+    ccl_test_hook(path, lds_runs);
+    return VA_OK;
+}
+
 int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, double sigma,
                     void *stream)
 {

@@ -1339,17 +1339,24 @@ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_
 }  // namespace
 
 // the per-frame LDS kernel takes frames whose row table and row stages leave room for at least
-// kMinLdsRuns runs, in batches of at least kMinFramesForFrameKernel frames; VA_CCL_LEGACY=1 (test
-// hook) forces the chip-wide multi-pass path, VA_CCL_LDS_RUNS=n the per-frame kernel with a small table
-// (its large-frame mode) whatever the batch size
+// kMinLdsRuns runs, in batches of at least kMinFramesForFrameKernel frames
+// test hook (va_test_hook_labelling): 0 = the library chooses, 1 = chip-wide passes, 2 = per-frame
+// kernel whatever the batch size; g_ccl_lds_runs > 0 caps the per-frame kernel's run table
+static int g_ccl_path = 0;
+static int g_ccl_lds_runs = 0;
+void ccl_test_hook(int path, int lds_runs)
+{
+    g_ccl_path = path;
+    g_ccl_lds_runs = lds_runs;
+}
+
 bool ccl_frame_kernel_used(int n, int h, int w)
 {
-    const char *e = getenv("VA_CCL_LEGACY");
-    if (e && atoi(e) != 0)
+    if (g_ccl_path == 1)
         return false;
     // one CU per frame pays off from about a third of the chip's CUs; smaller batches are
     // spread over all CUs by the chip-wide passes
-    if (n < kMinFramesForFrameKernel && !getenv("VA_CCL_LDS_RUNS"))
+    if (n < kMinFramesForFrameKernel && g_ccl_path != 2)
         return false;
     const int w32 = words_per_row(w);
     // larger frames (4K) overflow the run table too often and leave CUs idle: chip-wide passes
@@ -1425,8 +1432,8 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     if (ccl_frame_kernel_used(n, h, w)) {
         // one workgroup per frame, forest in LDS
         FrameLayout lay = frame_layout(h, w32);
-        if (const char *e = getenv("VA_CCL_LDS_RUNS"))    // test hook: force the hand-back
-            lay.lds_runs = max(0, min(lay.lds_runs, atoi(e)));
+        if (g_ccl_lds_runs > 0)                            // test hook: force the large-frame mode
+            lay.lds_runs = min(lay.lds_runs, g_ccl_lds_runs);
         const int vec = (w32 % 4 == 0) && aligned(bits, 16);
 #define VA_FRAME_LAUNCH(C8, NCH) \
     ccl_frame_kernel<C8, NCH><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, vec)

@@ -167,6 +167,7 @@ size_t ccl_workspace_bytes(int n, int h, int w);
 // true: launch_ccl labels with one workgroup per frame (forest in LDS) and needs no planted
 // forest; false: chip-wide multi-pass path (frames taller than the LDS row table, or the test hook)
 bool ccl_frame_kernel_used(int n, int h, int w);
+void ccl_test_hook(int path, int lds_runs);   // see va_test_hook_labelling
 size_t ccl_rows_workspace_bytes(int n, int h);   // launch_ccl's workspace (the caller owns the bit mask)
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,

@@ -108,6 +108,7 @@ SIGNATURES = {
     "va_pipeline_stage_times": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "va_gaussian_u8_generic": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "va_gaussian_u8_valu": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
+    "va_test_hook_labelling": (_i, [_i, _i]),
     "va_morph_bits_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "va_comm_unique_id": (_i, [_vp]),
     "va_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
