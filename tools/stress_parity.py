@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the fused chain against the CPU oracle (run on an MI355X):
+    python tools/stress_parity.py [seconds] [seed]
+Random frame sizes (incl. widths the matrix-core Gaussian / per-frame labelling kernels do and do
+not take), sigmas, thresholds, morphology chains, connectivities and batch sizes (>= 96 frames so
+that the per-frame labelling kernel runs). Prints one line per case, exits non-zero on a mismatch."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "video-analysis_amd"))
+from oracle import oracle as O          # noqa: E402  (checker only)
+from video.engine import FrameEngine    # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    O.build()
+    t_end = time.time() + budget
+    case = 0
+    codes = {"erode": O.ERODE, "dilate": O.DILATE}
+    while time.time() < t_end:
+        case += 1
+        big = rng.random() < 0.15                      # full-width frames now and then
+        h = int(rng.integers(32, 200)) if not big else int(rng.integers(100, 420))
+        w = int(rng.choice([64, 80, 96, 112, 128, 160, 208, 256, 272, 320, int(rng.integers(33, 300))]))
+        if big:
+            w = int(rng.choice([640, 1280, 1920, 1936, 2048, 2064]))
+        n = int(rng.choice([1, 3, 7, 96, 100, 130])) if not big else int(rng.choice([2, 97]))
+        sigma = float(rng.choice([0.6, 0.8, 1.0, 1.7, 2.0, 3.0, 4.2, 5.0, 5.3, 6.0]))
+        thresh = int(rng.integers(5, 60))
+        conn = int(rng.choice([4, 8]))
+        bg = str(rng.choice(["mean", "none"]))
+        nm = int(rng.integers(0, 3))
+        morph = tuple((str(rng.choice(["erode", "dilate"])), "rect", int(rng.choice([3, 5, 7]))) for _ in range(nm))
+        base = rng.normal(100, 10, (h, w))
+        clip = np.empty((n, h, w), np.uint8)
+        yy, xx = np.mgrid[:h, :w]
+        nb = int(rng.integers(1, 8))
+        cx, cy = rng.uniform(0, w, nb), rng.uniform(0, h, nb)
+        vx, vy = rng.uniform(-2, 2, nb), rng.uniform(-2, 2, nb)
+        rad = rng.uniform(3, 25, nb)
+        for t in range(n):
+            f = base + rng.normal(0, 4, (h, w))
+            for k in range(nb):
+                f[(xx - cx[k] - vx[k] * t) ** 2 + (yy - cy[k] - vy[k] * t) ** 2 <= rad[k] ** 2] += 60
+            f[rng.random((h, w)) < 0.003] = 255
+            clip[t] = np.clip(f, 0, 255).astype(np.uint8)
+        eng = FrameEngine(size=(w, h), max_batch=n, background=None if bg == "none" else bg, sigma=sigma,
+                          thresh=thresh, morphology=morph, connectivity=conn)
+        out = eng.run(clip, want=("filtered", "mask", "labels", "counts"))
+        eng.close()
+        cur = clip
+        if bg == "mean":
+            cur, _ = O.bg_mean_u8(clip)
+        blur = O.gaussian_u8(cur, sigma)
+        m = O.threshold_u8(blur, thresh)
+        for op, _, k in morph:
+            m = O.morph_u8(m, codes[op], O.RECT, k)
+        rl, rc = O.label_batch(m, conn)
+        ok = (np.array_equal(out["filtered"], blur) and np.array_equal(out["mask"], m)
+              and np.array_equal(out["labels"], rl) and np.array_equal(out["counts"], rc))
+        print("case %d: n=%d %dx%d sigma=%.1f t=%d conn=%d bg=%s morph=%s -> %s"
+              % (case, n, w, h, sigma, thresh, conn, bg, morph, "ok" if ok else "MISMATCH"), flush=True)
+        if not ok:
+            for nmk, a, b in (("filtered", out["filtered"], blur), ("mask", out["mask"], m), ("labels", out["labels"], rl)):
+                print("   ", nmk, "differs at", int((a != b).sum()), "elements")
+            sys.exit(1)
+    print("all %d cases ok" % case)
+
+
+if __name__ == "__main__":
+    main()
