@@ -47,10 +47,11 @@ def gather_counts(local_counts, n_frames=None, group=None):
     if local_counts.numel() != sizes[dist.get_rank(group)]:
         raise ValueError("rank %d holds %d counts, its shard has %d frames"
                          % (dist.get_rank(group), local_counts.numel(), sizes[dist.get_rank(group)]))
+    recv = torch.empty(world * cap, dtype=torch.int32, device=local_counts.device)
+    if all(s == cap for s in sizes):          # equal shards: the counts go out as they are
+        dist.all_gather_into_tensor(recv, local_counts.contiguous(), group=group)
+        return recv
     send = torch.zeros(cap, dtype=torch.int32, device=local_counts.device)
     send[:local_counts.numel()] = local_counts
-    recv = torch.empty(world * cap, dtype=torch.int32, device=local_counts.device)
     dist.all_gather_into_tensor(recv, send, group=group)
-    if all(s == cap for s in sizes):
-        return recv
     return torch.cat([recv[r * cap:r * cap + sizes[r]] for r in range(world)])
