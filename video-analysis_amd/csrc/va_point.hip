@@ -100,12 +100,12 @@ bg_reciprocals_kernel(double *__restrict__ y, long long n_seen, int n)
         y[f] = 1.0 / (double)(n_seen + f + 1);
 }
 
+template <int V>
 __global__ void __launch_bounds__(kBlock)
 bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff,
                        double *__restrict__ mean, const double *__restrict__ recip,
                        long long n_seen, int n, size_t px)
 {
-    constexpr int V = 8;
     size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * V;
     if (i0 >= px)
         return;
@@ -113,7 +113,7 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
 #pragma unroll
     for (int k = 0; k < V; k++)
         m[k] = mean[i0 + k];
-    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    typedef unsigned int v2u __attribute__((ext_vector_type(V / 4)));
     // frames and differences are one-touch streams: non-temporal loads/stores keep them out of L2.
     // Frames are walked in groups of kAhead: the next group's loads are issued before this
     // group's arithmetic (only ~4 waves per SIMD exist: 8 px per thread), so a load has kAhead
@@ -141,7 +141,7 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
             if (f >= n)
                 break;
             uint8_t p[V], o[V];
-            memcpy(p, &cur[j], 8);
+            memcpy(p, &cur[j], V);
             const double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
             const double y = recip[f];
 #pragma unroll
@@ -152,7 +152,7 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
             }
             if (diff) {
                 v2u v;
-                memcpy(&v, o, 8);
+                memcpy(&v, o, V);
                 __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(diff + (size_t)f * px + i0));
             }
         }
@@ -423,8 +423,13 @@ int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, 
             if (vec && recip_scratch) {
                 bg_reciprocals_kernel<<<cdiv(n, kBlock), kBlock, 0, st>>>(recip_scratch, n_seen, n);
                 VA_LAUNCH_CHECK("bg_reciprocals_kernel");
-                bg_mean_u8_fast_kernel<<<grid, kBlock, 0, st>>>(fr, df, (double *)state,
-                                                               recip_scratch, n_seen, n, px);
+                // 16 px per thread when the streams allow 16-byte pieces (1 KB per wave instruction)
+                if (px % 16 == 0 && aligned(fr, 16) && (!df || aligned(df, 16)))
+                    bg_mean_u8_fast_kernel<16><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
+                        fr, df, (double *)state, recip_scratch, n_seen, n, px);
+                else
+                    bg_mean_u8_fast_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (double *)state,
+                                                                      recip_scratch, n_seen, n, px);
             } else if (vec)
                 bg_mean_u8_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, n_seen, n, px);
             else
