@@ -146,7 +146,8 @@ def test_running_mean_bit_exact(ops, golden, oracle):
 
 def test_running_mean_split_batches_and_odd_sizes(ops, oracle):
     rng = np.random.default_rng(21)
-    for shape in ((37, 5, 7), (20, 33, 41), (9, 16, 24)):       # px % 8 != 0 and == 0
+    # px % 8 != 0 (scalar kernel), px % 16 == 0 (16 px per thread), px % 16 == 8 (8 px per thread)
+    for shape in ((37, 5, 7), (20, 33, 41), (9, 16, 24), (11, 5, 8), (6, 3, 24)):
         fr = rng.integers(0, 256, shape, dtype=np.uint8)
         rd, rm = oracle.bg_mean_u8(fr)
         model = ops.BackgroundModel(shape[1:], "mean")
