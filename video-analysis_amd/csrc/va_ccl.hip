@@ -452,8 +452,9 @@ ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
 //     backward search for a run's first pixel, no node in global memory;
 //   * every wave sweeps 8 rows at a time: the rows (contiguous in memory) are copied into the
 //     wave's LDS stage with coalesced 16-byte loads, lanes (row, word group) then work on LDS;
-//   * contacts between rows are first QUEUED per wave, then united with all lanes busy
-//     (in-place unions serialise: a wave runs the longest lane's chain at every word);
+//   * contacts between rows are first QUEUED per wave (slots from a wave-wide DPP scan of the
+//     lanes' contact counts, plain LDS stores), then united with all lanes busy (in-place
+//     unions serialise: a wave runs the longest lane's chain at every word);
 //     unions are ds_min atomics towards the smaller id, so the root is again the component's
 //     first run in raster order and label = 1 + number of roots with a smaller id;
 //   * the only global traffic is the bit mask (read three times, L2-resident after the first)

@@ -14,8 +14,8 @@
 //
 // A workgroup of four waves owns a 128-column strip of one frame and marches down it 32 rows per
 // step; each wave computes one 32-column tile.  The input tile (32 rows x 160 columns with the
-// halo) is loaded by the whole workgroup, whole cache lines per row, so the L2->L1 traffic is
-// 3 lines per 128 useful bytes (per-wave 64-byte windows moved 6, and were L2-bandwidth bound):
+// halo) is loaded by the whole workgroup, whole cache lines per row (3 lines per 128 useful
+// bytes; per-wave 64-byte windows moved 6):
 //
 //   global --16 B/lane, rows reflected (BORDER_REFLECT_101), prefetched one step ahead-->
 //   registers: x ^ 0x80 (u8 -> i8, x' = x - 128) --> LDS tile (double buffered, one barrier/step)
@@ -29,8 +29,10 @@
 //              the previous and the current row tile (64 input rows -> 32 output rows);
 //              every additive constant of the u8->i8 shifts enters through the C operand
 //   output   : t = (hi << 8) + lo = acc_min - 1 - acc, so "blur > thresh" is t's sign bit:
-//              v_alignbit collects the 16 columns a lane holds, one shuffle joins the two half
-//              rows, lanes 0..31 store one mask word each; u8 output: (acc + 2^15) >> 16.
+//              v_alignbit collects the 16 columns a lane holds, v_permlane32_swap joins the two
+//              half rows; u8 output: (acc + 2^15) >> 16.  Mask words and u8 tiles gather in LDS
+//              and leave as 16-byte buffer stores (4-byte stores scattered over 32 rows per
+//              instruction cost 30 % of the kernel although they add no HBM bytes).
 //
 // Exactness: with w_k the q8.8 taps (sum S <= 256, each <= 127) and x' = x - 128,
 //   row:  sum w x = X + 128 S,  X = 256 hi + lo' + 128  (hi = X >> 8 signed, lo' = (X & 255) - 128)
