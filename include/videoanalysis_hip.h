@@ -129,6 +129,11 @@ int va_mono_mean_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t pixels, voi
  *           clip to [fmin,fmax]; (f - fmin)*alpha + tmin in float64; astype(uint8) */
 int va_normalize_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t count, double fmin,
                     double fmax, double alpha, double tmin, void *stream);
+/* replaces  np.rot90(frame, angle // 90), FilterRotate._process_frame, video/filters.py:339-344
+ * (N4): n frames (h, w) of opaque elem_bytes-byte pixels (channels x dtype: 1, 2, 3, 4, 6, 8 or
+ * 12 bytes) turned k quarter turns counter-clockwise; output frames are (w, h) for odd k. */
+int va_rot90(const void *src_dev, void *dst_dev, int n, int h, int w, int elem_bytes, int k,
+             void *stream);
 
 /* ------------------------------------------------------------------ A6 morphology
  * replaces  cv2.erode / cv2.dilate(img, cv2.getStructuringElement(shape, (k, k))),

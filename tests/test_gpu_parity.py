@@ -129,6 +129,36 @@ def test_gaussian_1080p_properties(ops, oracle):
     assert np.array_equal(ops.gaussian_blur(im[:, ::-1, ::-1].copy(), 5.0), out[:, ::-1, ::-1])
 
 
+# ------------------------------------------------------------------------------ rotation
+@pytest.mark.parametrize("shape,dtype,color", [((3, 37, 53), np.uint8, False), ((2, 64, 96), np.uint8, False),
+                                               ((1, 33, 31, 3), np.uint8, True), ((2, 40, 70), np.int16, False),
+                                               ((2, 31, 65), np.float32, False), ((1, 20, 45, 3), np.float32, True),
+                                               ((45, 100), np.float64, False), ((1, 1, 7), np.uint8, False)])
+def test_rot90_matches_numpy(ops, shape, dtype, color):
+    """N4 FilterRotate (video/filters.py:339-344): np.rot90 in the image plane, every quarter turn"""
+    rng = np.random.default_rng(sum(shape))
+    a = (rng.random(shape) * 200).astype(dtype)
+    axes = (0, 1) if a.ndim == (3 if color else 2) else (1, 2)
+    for k in (0, 1, 2, 3, 5, -1):
+        assert np.array_equal(ops.rot90(a, k, color=color), np.rot90(a, k, axes=axes)), (shape, k)
+
+
+def test_filter_rotate_plumbing(ops):
+    from video.io.memory import VideoMemory
+    from video.filters import FilterRotate
+    rng = np.random.default_rng(3)
+    clip = rng.integers(0, 256, (5, 30, 44), dtype=np.uint8)
+    for angle in (0, 90, 180, 270, 450):
+        rot = FilterRotate(VideoMemory(clip.copy()), angle)
+        k = (angle % 360) // 90
+        assert rot.size == ((30, 44) if k & 1 else (44, 30))       # (width, height)
+        assert len(rot) == 5
+        for i, frame in enumerate(rot):
+            assert np.array_equal(frame, np.rot90(clip[i], k))
+    with pytest.raises(ValueError):
+        FilterRotate(VideoMemory(clip), 45)
+
+
 # -------------------------------------------------------------------------- background
 def test_running_mean_bit_exact(ops, golden, oracle):
     for n in (1, 2, 8, 64, 256):

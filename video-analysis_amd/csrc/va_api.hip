@@ -375,6 +375,11 @@ int va_normalize_u8(const uint8_t *src, uint8_t *dst, size_t count, double fmin,
     return launch_normalize_u8(src, dst, count, fmin, fmax, alpha, tmin, as_stream(stream));
 }
 
+int va_rot90(const void *src, void *dst, int n, int h, int w, int elem_bytes, int k, void *stream)
+{
+    return launch_rot90(src, dst, n, h, w, elem_bytes, k, as_stream(stream));
+}
+
 // ------------------------------------------------------------------------------ morphology
 int va_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op, int shape,
                 int ksize, void *stream)

@@ -521,6 +521,99 @@ int launch_mono_mean(const uint8_t *src, uint8_t *dst, size_t pixels, hipStream_
     return VA_OK;
 }
 
+// ---- np.rot90 (FilterRotate, video/filters.py:341) --------------------------------------------
+// Pixels are opaque E-byte elements (channels x dtype).  A 32 x 32 tile goes through LDS so that
+// both the reads and the writes of a wave are rows of consecutive elements, whatever the turn.
+template <typename E>
+__global__ void __launch_bounds__(kBlock)
+rot90_kernel(const E *__restrict__ src, E *__restrict__ dst, int h, int w, int k)
+{
+    __shared__ E tile[32][33];
+    const int ho = (k & 1) ? w : h, wo = (k & 1) ? h : w;     // output frame
+    const int tiles_x = (wo + 31) >> 5, tiles_y = (ho + 31) >> 5;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const size_t f = t / tiles_y;
+    const E *in = src + f * (size_t)h * w;
+    E *out = dst + f * (size_t)h * w;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8 threads
+    // output tile (i0.., j0..); out[i][j] = in[si][sj] with
+    //   k=1: (j, w-1-i)   k=2: (h-1-i, w-1-j)   k=3: (h-1-j, i)   k=0: (i, j)
+    const int i0 = ty * 32, j0 = tx * 32;
+    // load: walk the SOURCE rows of the tile so that lx runs along a source row
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int a = ly + r, b = lx;       // tile-local coordinates in the source orientation
+        int si, sj;
+        if (k == 1) {            // source rows = output columns j, source cols descend with i
+            si = j0 + a;
+            sj = w - 1 - (i0 + b);
+        } else if (k == 2) {
+            si = h - 1 - (i0 + a);
+            sj = w - 1 - (j0 + b);
+        } else if (k == 3) {
+            si = h - 1 - (j0 + a);
+            sj = i0 + b;
+        } else {
+            si = i0 + a;
+            sj = j0 + b;
+        }
+        if (si >= 0 && si < h && sj >= 0 && sj < w)
+            tile[a][b] = in[(size_t)si * w + sj];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int i = i0 + ly + r, j = j0 + lx;
+        if (i < ho && j < wo) {
+            // which (a, b) of the load holds out[i][j]?
+            const int di = ly + r, dj = lx;
+            E v;
+            if (k == 1)
+                v = tile[dj][di];        // si = j, sj = w-1-i  ->  a = j-j0, b = i-i0
+            else if (k == 3)
+                v = tile[dj][di];        // si = h-1-j, sj = i  ->  a = j-j0, b = i-i0
+            else
+                v = tile[di][dj];
+            out[(size_t)i * wo + j] = v;
+        }
+    }
+}
+
+struct Elem3 { uint8_t b[3]; };
+struct Elem6 { uint16_t b[3]; };
+struct Elem12 { uint32_t b[3]; };
+
+int launch_rot90(const void *src, void *dst, int n, int h, int w, int elem_bytes, int k,
+                 hipStream_t st)
+{
+    VA_REQUIRE(src && dst && src != dst, "va_rot90: src/dst must be distinct non-NULL");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_rot90: bad shape (%d,%d,%d)", n, h, w);
+    k &= 3;
+    if (n == 0)
+        return VA_OK;
+    const int ho = (k & 1) ? w : h, wo = (k & 1) ? h : w;
+    const size_t blocks = (size_t)n * ((ho + 31) / 32) * ((wo + 31) / 32);
+    VA_REQUIRE(blocks < ((size_t)1 << 31), "va_rot90: too many tiles");
+#define VA_ROT(T) rot90_kernel<T><<<(unsigned)blocks, kBlock, 0, st>>>((const T *)src, (T *)dst, h, w, k)
+    switch (elem_bytes) {
+    case 1: VA_ROT(uint8_t); break;
+    case 2: VA_ROT(uint16_t); break;
+    case 3: VA_ROT(Elem3); break;
+    case 4: VA_ROT(uint32_t); break;
+    case 6: VA_ROT(Elem6); break;
+    case 8: VA_ROT(uint64_t); break;
+    case 12: VA_ROT(Elem12); break;
+    default:
+        VA_REQUIRE(false, "va_rot90: unsupported pixel size of %d bytes", elem_bytes);
+    }
+#undef VA_ROT
+    VA_LAUNCH_CHECK("rot90_kernel");
+    return VA_OK;
+}
+
 int launch_normalize_u8(const uint8_t *src, uint8_t *dst, size_t count, double fmin, double fmax,
                         double alpha, double tmin, hipStream_t st)
 {

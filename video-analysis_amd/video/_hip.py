@@ -86,6 +86,7 @@ SIGNATURES = {
     "va_time_difference_u8": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "va_threshold_u8": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
     "va_mono_mean_u8": (_i, [_vp, _vp, _sz, _vp]),
+    "va_rot90": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "va_normalize_u8": (_i, [_vp, _vp, _sz, _d, _d, _d, _d, _vp]),
     "va_morph_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "va_label_workspace_bytes": (_sz, [_i, _i, _i]),

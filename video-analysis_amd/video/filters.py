@@ -256,6 +256,28 @@ class _FrameIndexFilter(VideoFilterBase):
         return self.get_frame(self._frame_pos)
 
 
+class FilterRotate(VideoFilterBase):
+    """returns the video rotated in counter-clockwise direction (reference :319-344):
+    `np.rot90(frame, angle // 90)` on the GPU"""
+
+    def __init__(self, source, angle=0):
+        angle = angle % 360
+        if angle in (0, 180):
+            size = source.size
+        elif angle in (90, 270):
+            size = (source.size[1], source.size[0])
+        else:
+            raise ValueError('angle must be from [0, 90, 180, 270] but was %s' % angle)
+        self.angle = angle
+        super(FilterRotate, self).__init__(source, size=size)
+
+    def _process_frame(self, frame):
+        frame = np.asarray(frame)
+        if self.angle:
+            frame = ops.rot90(frame, self.angle // 90, color=frame.ndim == 3)
+        return super(FilterRotate, self)._process_frame(frame)
+
+
 class FilterReplicate(_FrameIndexFilter):
     """plays the source `count` times in a row (reference :396-430)"""
 

@@ -167,6 +167,23 @@ def mono_mean(frames):
     return _pointwise_u8(_hip.lib().va_mono_mean_u8, a, a.shape[:-1], a.size // 3, None)
 
 
+def rot90(frames, k=1, color=False):
+    """np.rot90(frame, k) per frame (FilterRotate, video/filters.py:339-344).
+    frames: (H,W) / (N,H,W), with color=True (H,W,C) / (N,H,W,C); any dtype whose pixel
+    (channels x itemsize) is 1, 2, 3, 4, 6, 8 or 12 bytes."""
+    arr, n, fshape, single = _as_batch(np.ascontiguousarray(frames), 3 if color else 2)
+    h, w, c = _hwc(fshape)
+    k = int(k) % 4
+    out_shape = ((w, h) if k & 1 else (h, w)) + ((c,) if color else ())
+    src = DeviceBuffer.from_array(arr)
+    dst = DeviceBuffer(arr.nbytes)
+    check(_hip.lib().va_rot90(src.ptr, dst.ptr, n, h, w, c * arr.dtype.itemsize, k, None))
+    out = dst.download((n,) + out_shape, arr.dtype)
+    src.free()
+    dst.free()
+    return out[0] if single else out
+
+
 def normalize(frames, fmin, fmax, alpha, tmin):
     """clip + affine + astype(uint8)  (FilterNormalize, video/filters.py:126-132)"""
     a = np.ascontiguousarray(frames, np.uint8)
