@@ -275,8 +275,9 @@ int va_gaussian_u8_valu(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, 
 int va_morph_bits_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int op,
                      int shape, int ksize, void *stream);
 /* pins the labelling code path of every later va_label_i32 / va_largest_contour / pipeline call
- * of this process: path 0 = library's choice (per-frame LDS kernel for batches of >= 96 frames
- * up to about 1080p, chip-wide passes otherwise), 1 = chip-wide passes, 2 = per-frame kernel;
+ * of this process: path 0 = library's choice (per-frame LDS kernel when its cost model beats the
+ * chip-wide passes: frames up to about 1080p in batches of roughly 80 frames or more, small
+ * frames in any batch; chip-wide passes otherwise), 1 = chip-wide passes, 2 = per-frame kernel;
  * lds_runs > 0 caps the per-frame kernel's run table (frames above it take its large-frame mode) */
 int va_test_hook_labelling(int path, int lds_runs);
 

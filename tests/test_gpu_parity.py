@@ -279,7 +279,7 @@ def ccl_mode(request):
     test hooks: one workgroup per frame with the forest in LDS (the default for large batches), the same kernel's
     large-frame mode (forest in the label image; forced by a tiny LDS budget), and the chip-wide
     multi-pass path that frames taller than the LDS row table take"""
-    # (without a hook the library picks by batch size: per-frame kernel from 96 frames up)
+    # (without a hook the library picks by a cost model of frame size and batch size)
     path, lds_runs = {"frame-lds": (2, 0), "frame-large": (2, 7), "chip-wide": (1, 0)}[request.param]
     from video import _hip
     _hip.check(_hip.lib().va_test_hook_labelling(path, lds_runs))

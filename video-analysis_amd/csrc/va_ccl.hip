@@ -470,7 +470,6 @@ constexpr int kFrameRowsPerIter = kFrameWaves * kRowsPerWave;     // 128 rows pe
 constexpr int kFrameLdsWords = 37 * 1024;                         // 148 KB, partitioned per launch
 constexpr int kQueue = 128;                                       // queued pairs per wave
 constexpr int kMinLdsRuns = 4096;                                 // else: chip-wide path
-constexpr int kMinFramesForFrameKernel = 96;                      // batches below: chip-wide path
 constexpr int kMaxFrameWords = 80 * 1024;                         // mask words per frame (1080p: 64.8 k)
 constexpr int kNonRootBit = 1 << 30;
 
@@ -1340,7 +1339,7 @@ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_
 }  // namespace
 
 // the per-frame LDS kernel takes frames whose row table and row stages leave room for at least
-// kMinLdsRuns runs, in batches of at least kMinFramesForFrameKernel frames
+// kMinLdsRuns runs, for batches large enough that one CU per frame beats the chip-wide passes
 // test hook (va_test_hook_labelling): 0 = the library chooses, 1 = chip-wide passes, 2 = per-frame
 // kernel whatever the batch size; g_ccl_lds_runs > 0 caps the per-frame kernel's run table
 static int g_ccl_path = 0;
@@ -1355,10 +1354,15 @@ bool ccl_frame_kernel_used(int n, int h, int w)
 {
     if (g_ccl_path == 1)
         return false;
-    // one CU per frame pays off from about a third of the chip's CUs; smaller batches are
-    // spread over all CUs by the chip-wide passes
-    if (n < kMinFramesForFrameKernel && g_ccl_path != 2)
-        return false;
+    // One CU per frame costs the same whatever the batch size (up to one frame per CU), the
+    // chip-wide passes scale with the batch: measured ~0.106 ms per 1080p frame set against
+    // ~0.277 ms per 256 x 1080p frames plus ~0.03 ms of launches (four more kernels).
+    {
+        const double wf = (double)h * words_per_row(w) / 64800.0;     // frame size in 1080p frames
+        const double t_frame = 0.106 * wf + 0.01, t_chip = 0.277 * wf * n / 256.0 + 0.03;
+        if (t_frame >= t_chip && g_ccl_path != 2)
+            return false;
+    }
     const int w32 = words_per_row(w);
     // larger frames (4K) overflow the run table too often and leave CUs idle: chip-wide passes
     if ((long long)h * w32 > kMaxFrameWords)
