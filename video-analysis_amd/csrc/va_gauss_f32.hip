@@ -336,13 +336,14 @@ gauss_row2_f32_kernel(const float *__restrict__ src, float *__restrict__ tmp, si
     }
 }
 
-constexpr int kColTileRows = 32, kColTileCols = 128;
+constexpr int kColTileRows = 64, kColTileCols = 64;      // outputs per workgroup: 8 row groups x 32 column pairs
+constexpr int kColStride = kColTileCols + 2;             // floats per staged row (even: float2 reads stay aligned)
 
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 4)
 gauss_col2_f32_kernel(const float *__restrict__ tmp, float *__restrict__ dst, int h, int rw, int ncolt,
                       int nrowt, TapsF32 taps, int vec4)
 {
-    extern __shared__ float tile[];     // (32 + 2r) rows x 128 samples; row j <-> image row y0 - r + j
+    extern __shared__ float tile[];     // (64 + 2r) rows x 64 samples; row j <-> image row y0 - r + j
     const int r = taps.ksize >> 1;
     int b = blockIdx.x;
     const int ct = b % ncolt;
@@ -352,48 +353,67 @@ gauss_col2_f32_kernel(const float *__restrict__ tmp, float *__restrict__ dst, in
     const int x0 = ct * kColTileCols, y0 = rt * kColTileRows;
     const float *frame = tmp + fz * (size_t)h * rw;
     const int nrows = kColTileRows + 2 * r;
-    for (int idx = threadIdx.x; idx < nrows * (kColTileCols / 4); idx += kBlock) {
-        const int row = idx >> 5, c4 = (idx & 31) * 4;
-        const float *g = frame + (size_t)reflect101(y0 - r + row, h) * rw + x0 + c4;
-        f4 v;
-        if (vec4 && x0 + c4 + 3 < rw) {
-            v = *reinterpret_cast<const f4 *>(g);
-        } else {
-            v.x = x0 + c4 + 0 < rw ? g[0] : 0.0f;
-            v.y = x0 + c4 + 1 < rw ? g[1] : 0.0f;
-            v.z = x0 + c4 + 2 < rw ? g[2] : 0.0f;
-            v.w = x0 + c4 + 3 < rw ? g[3] : 0.0f;
+    // stage: 16 float4 per row; loads in batches of four so that several are in flight
+    const int items = nrows * (kColTileCols / 4);
+    for (int base = 0; base < items; base += 4 * kBlock) {
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = min(base + u * kBlock + (int)threadIdx.x, items - 1);
+            const int row = idx >> 4, c4 = (idx & 15) * 4;
+            const float *g = frame + (size_t)reflect101(y0 - r + row, h) * rw + x0 + c4;
+            if (vec4 && x0 + c4 + 3 < rw) {
+                v[u] = *reinterpret_cast<const f4 *>(g);
+            } else {
+                v[u].x = x0 + c4 + 0 < rw ? g[0] : 0.0f;
+                v[u].y = x0 + c4 + 1 < rw ? g[1] : 0.0f;
+                v[u].z = x0 + c4 + 2 < rw ? g[2] : 0.0f;
+                v[u].w = x0 + c4 + 3 < rw ? g[3] : 0.0f;
+            }
         }
-        *reinterpret_cast<f4 *>(tile + row * kColTileCols + c4) = v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = base + u * kBlock + (int)threadIdx.x;
+            if (idx < items) {
+                float *d = tile + (idx >> 4) * kColStride + (idx & 15) * 4;
+                *reinterpret_cast<f2 *>(d) = f2{v[u].x, v[u].y};
+                *reinterpret_cast<f2 *>(d + 2) = f2{v[u].z, v[u].w};
+            }
+        }
     }
     __syncthreads();
 
-    const int cp = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int cp = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int col = x0 + 2 * cp;
     if (col >= rw)
         return;
-    const f2 *tcol = reinterpret_cast<const f2 *>(tile) + cp;      // row stride: 64 f2
+    constexpr int RS = kColStride / 2;                                // row stride in f2
+    const f2 *tcol = reinterpret_cast<const f2 *>(tile) + cp;
     const int tr0 = 8 * rg + r;                                      // tile row of output j = 0
     f2 up[8], dn[8], acc[8];
     {
         const f2 wc = f2{taps.t[r], taps.t[r]};
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            up[j] = dn[j] = tcol[(tr0 + j) * 64];
+            up[j] = dn[j] = tcol[(tr0 + j) * RS];
             acc[j] = pk_fma(up[j], wc, f2{0.0f, 0.0f});
         }
     }
     for (int k0 = 1; k0 <= r; k0 += 8) {   // k0 = 1 (mod 8): every ring slot below is static
         float wk8[8];
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-            wk8[t] = taps.t[min(r + k0 + t, kMaxTaps)];
+        f2 nu[8], nd[8];                   // this period's sixteen rows, read from LDS in one batch
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-            const int k = k0 + t;
-            if (k <= r) {                               // uniform
-                up[t] = tcol[(tr0 + 7 + k) * 64];       // row y+7+k replaces row y+k-1
-                dn[7 - t] = tcol[(tr0 - k) * 64];       // row y-k   replaces row y+8-k
+            const int k = min(k0 + t, r);
+            wk8[t] = taps.t[r + k];
+            nu[t] = tcol[(tr0 + 7 + k) * RS];   // row y+7+k replaces row y+k-1
+            nd[t] = tcol[(tr0 - k) * RS];       // row y-k   replaces row y+8-k
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            if (k0 + t <= r) {                          // uniform
+                up[t] = nu[t];
+                dn[7 - t] = nd[t];
                 const f2 w2 = f2{wk8[t], wk8[t]};
 #pragma unroll
                 for (int j = 0; j < 8; j++)
@@ -426,7 +446,7 @@ bool gauss_f32_packed_supported(int w, int c, const TapsF32 &taps)
         return false;
     if (((size_t)rw + 2 * (size_t)r * c + 32) * sizeof(f2) > 64 * 1024)
         return false;
-    return (size_t)(kColTileRows + 2 * r) * kColTileCols * sizeof(float) <= 60 * 1024;
+    return (size_t)(kColTileRows + 2 * r) * kColStride * sizeof(float) <= 60 * 1024;
 }
 
 }  // namespace
@@ -464,7 +484,7 @@ int launch_gauss_f32_fast(const float *src, float *dst, float *scratch, int n, i
             gauss_row2_f32_kernel<3, 15><<<pairs, kRowThreads, lds2, st>>>(src, scratch, total_rows, w, taps, vec4s);
         VA_LAUNCH_CHECK("gauss_row2_f32_kernel");
         const int ncolt = cdiv(rw, kColTileCols), nrowt = cdiv(h, kColTileRows);
-        const size_t ldsc = (size_t)(kColTileRows + 2 * r) * kColTileCols * sizeof(float);
+        const size_t ldsc = (size_t)(kColTileRows + 2 * r) * kColStride * sizeof(float);
         const int vec4c = (rw % 4 == 0) && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0) &&
                           (reinterpret_cast<uintptr_t>(dst) % 8 == 0);
         gauss_col2_f32_kernel<<<(unsigned)((size_t)ncolt * nrowt * n), kBlock, ldsc, st>>>(
