@@ -188,19 +188,40 @@ __device__ __forceinline__ SpanCtx span_ctx_in_frame(int f, int h, int w32)
 // ---- K1: every run's first pixel becomes a singleton tree ---------------------------------
 // (the *_span functions are the per-lane bodies: the chip-wide kernels below map lanes to rows
 // through blockIdx, the per-frame kernel's large-frame mode loops over its frame's rows)
-__device__ __forceinline__ void init_span(const uint32_t *row, int32_t *L, int y, int w, int w0,
-                                          int w1)
+// Words c0-1 .. c0+kGChunk of a mask row in global memory, every load issued before the first
+// use (clamped addresses, masked values): m[0] = word c0-1, m[1 + k] = word c0 + k, 0 outside
+// the row.  A word-by-word loop pays one L2 round trip per word.
+constexpr int kGChunk = 8;
+__device__ __forceinline__ void load_words(const uint32_t *row, int c0, int w32,
+                                           uint32_t (&m)[kGChunk + 2])
 {
-    uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
-    for (int wi = w0; wi < w1; wi++) {
-        const uint32_t m = row[wi];
-        uint32_t s = m & ~((m << 1) | prev);
-        prev = m >> 31;
-        while (s) {
-            int b = __ffs(s) - 1;
-            s &= s - 1;
-            int idx = y * w + (wi << 5) + b;
-            L[idx] = idx;
+#pragma unroll
+    for (int k = 0; k < kGChunk + 2; k++)
+        m[k] = row[min(max(c0 - 1 + k, 0), w32 - 1)];
+#pragma unroll
+    for (int k = 0; k < kGChunk + 2; k++) {
+        const int wi = c0 - 1 + k;
+        m[k] = (wi >= 0 && wi < w32) ? m[k] : 0u;
+    }
+}
+
+__device__ __forceinline__ void init_span(const uint32_t *row, int32_t *L, int y, int w, int w32,
+                                          int w0, int w1)
+{
+    for (int c0 = w0; c0 < w1; c0 += kGChunk) {
+        uint32_t mw[kGChunk + 2];
+        load_words(row, c0, w32, mw);
+#pragma unroll
+        for (int k = 0; k < kGChunk; k++) {
+            if (c0 + k >= w1)
+                break;
+            uint32_t s = mw[k + 1] & ~((mw[k + 1] << 1) | (mw[k] >> 31));
+            while (s) {
+                int b = __ffs(s) - 1;
+                s &= s - 1;
+                int idx = y * w + ((c0 + k) << 5) + b;
+                L[idx] = idx;
+            }
         }
     }
 }
@@ -213,7 +234,7 @@ ccl_init_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
     for (int i = blockIdx.y; i < nf; i += gridDim.y) {
         const SpanCtx c = span_ctx_in_frame(frame_at(fl, i), h, w32);
         if (c.valid)
-            init_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1);
+            init_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, w32, c.w0, c.w1);
     }
 }
 
@@ -224,6 +245,8 @@ __device__ __forceinline__ void link_span(const uint32_t *row, int32_t *L, int y
 {
     const uint32_t *up = row - w32;
     const int base = y * w, ubase = (y - 1) * w;
+    // (word-by-word: here the chunked form of the other passes was slower -- the walks and the
+    // backward searches of run_start dominate, and the unrolled body costs registers)
     uint32_t mp = w0 > 0 ? row[w0 - 1] : 0u, upv = w0 > 0 ? up[w0 - 1] : 0u;
     for (int wi = w0; wi < w1; wi++) {
         const uint32_t m = row[wi], u = up[wi];
@@ -278,24 +301,28 @@ ccl_link_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
 }
 
 // ---- K3: flatten every run to its root, count roots per row ---------------------------------
-__device__ __forceinline__ int flatten_span(const uint32_t *row, int32_t *L, int y, int w, int w0,
-                                            int w1)
+__device__ __forceinline__ int flatten_span(const uint32_t *row, int32_t *L, int y, int w, int w32,
+                                            int w0, int w1)
 {
     int cnt = 0;
-    uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
-    for (int wi = w0; wi < w1; wi++) {
-        const uint32_t m = row[wi];
-        uint32_t s = m & ~((m << 1) | prev);
-        prev = m >> 31;
-        while (s) {
-            int b = __ffs(s) - 1;
-            s &= s - 1;
-            int idx = y * w + (wi << 5) + b;
-            int r = find_root_ro(L, idx);
-            if (r == idx)
-                cnt++;
-            else
-                st_forest(L + idx, r);
+    for (int c0 = w0; c0 < w1; c0 += kGChunk) {
+        uint32_t mw[kGChunk + 2];
+        load_words(row, c0, w32, mw);
+#pragma unroll
+        for (int k = 0; k < kGChunk; k++) {
+            if (c0 + k >= w1)
+                break;
+            uint32_t s = mw[k + 1] & ~((mw[k + 1] << 1) | (mw[k] >> 31));
+            while (s) {
+                int b = __ffs(s) - 1;
+                s &= s - 1;
+                int idx = y * w + ((c0 + k) << 5) + b;
+                int r = find_root_ro(L, idx);
+                if (r == idx)
+                    cnt++;
+                else
+                    st_forest(L + idx, r);
+            }
         }
     }
     return cnt;
@@ -347,7 +374,7 @@ ccl_flatten_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labe
         const SpanCtx c = span_ctx_in_frame(frame_at(fl, i), h, w32);
         int cnt = 0;
         if (c.valid)
-            cnt = flatten_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1);
+            cnt = flatten_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, w32, c.w0, c.w1);
         cnt = row_sum(cnt);
         const int y = blockIdx.x * kSparseRowsPerBlock + (int)(threadIdx.x >> 6) * kRowsPerWave + c.lane;
         if (c.lane < kRowsPerWave && y < h)
@@ -391,22 +418,26 @@ ccl_rowscan_kernel(const int32_t *__restrict__ row_cnt, int32_t *__restrict__ ro
 
 // ---- K5: roots get their final label, stored negated ----------------------------------------
 // all lanes of the wave must call (shuffles); `valid` lanes own a row and a non-empty span
-__device__ __forceinline__ void rank_span(const uint32_t *row, int32_t *L, int y, int w, int w0,
-                                          int w1, int lane, bool valid, int row_offset)
+__device__ __forceinline__ void rank_span(const uint32_t *row, int32_t *L, int y, int w, int w32,
+                                          int w0, int w1, int lane, bool valid, int row_offset)
 {
-    // pass 1: roots in this lane's span
+    // pass 1: roots in this lane's span (every root test of a chunk is loaded before any is used)
     int nroots = 0;
     if (valid) {
-        uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
-        for (int wi = w0; wi < w1; wi++) {
-            const uint32_t m = row[wi];
-            uint32_t s = m & ~((m << 1) | prev);
-            prev = m >> 31;
-            while (s) {
-                int b = __ffs(s) - 1;
-                s &= s - 1;
-                int idx = y * w + (wi << 5) + b;
-                nroots += L[idx] == idx;
+        for (int c0 = w0; c0 < w1; c0 += kGChunk) {
+            uint32_t mw[kGChunk + 2];
+            load_words(row, c0, w32, mw);
+#pragma unroll
+            for (int k = 0; k < kGChunk; k++) {
+                if (c0 + k >= w1)
+                    break;
+                uint32_t s = mw[k + 1] & ~((mw[k + 1] << 1) | (mw[k] >> 31));
+                while (s) {
+                    int b = __ffs(s) - 1;
+                    s &= s - 1;
+                    int idx = y * w + ((c0 + k) << 5) + b;
+                    nroots += L[idx] == idx;
+                }
             }
         }
     }
@@ -415,17 +446,21 @@ __device__ __forceinline__ void rank_span(const uint32_t *row, int32_t *L, int y
         return;
     int k = row_offset + before;
     // pass 2: number them (roots still hold L[idx] == idx: only this lane rewrites its span)
-    uint32_t prev = w0 > 0 ? row[w0 - 1] >> 31 : 0u;
-    for (int wi = w0; wi < w1; wi++) {
-        const uint32_t m = row[wi];
-        uint32_t s = m & ~((m << 1) | prev);
-        prev = m >> 31;
-        while (s) {
-            int b = __ffs(s) - 1;
-            s &= s - 1;
-            int idx = y * w + (wi << 5) + b;
-            if (L[idx] == idx)
-                L[idx] = -(++k);
+    for (int c0 = w0; c0 < w1; c0 += kGChunk) {
+        uint32_t mw[kGChunk + 2];
+        load_words(row, c0, w32, mw);
+#pragma unroll
+        for (int q = 0; q < kGChunk; q++) {
+            if (c0 + q >= w1)
+                break;
+            uint32_t s = mw[q + 1] & ~((mw[q + 1] << 1) | (mw[q] >> 31));
+            while (s) {
+                int b = __ffs(s) - 1;
+                s &= s - 1;
+                int idx = y * w + ((c0 + q) << 5) + b;
+                if (L[idx] == idx)
+                    L[idx] = -(++k);
+            }
         }
     }
 }
@@ -437,7 +472,7 @@ ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
     const int nf = frames_listed(fl);
     for (int i = blockIdx.y; i < nf; i += gridDim.y) {
         const SpanCtx c = span_ctx_in_frame(frame_at(fl, i), h, w32);
-        rank_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, c.w0, c.w1, c.lane,
+        rank_span(bits + c.row * w32, labels + (size_t)c.f * h * w, c.y, w, w32, c.w0, c.w1, c.lane,
                   c.valid, c.valid ? row_off[c.row] : 0);
     }
 }
@@ -733,7 +768,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         for (int it = 0; it < sweeps; it++) {
             const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
             if (c.valid && c.w0 < c.w1)
-                init_span(fbits + (size_t)c.y * w32, L, c.y, w, c.w0, c.w1);
+                init_span(fbits + (size_t)c.y * w32, L, c.y, w, w32, c.w0, c.w1);
         }
         __syncthreads();
         for (int it = 0; it < sweeps; it++) {
@@ -744,7 +779,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         __syncthreads();
         for (int it = 0; it < sweeps; it++) {
             const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
-            int n = c.valid && c.w0 < c.w1 ? flatten_span(fbits + (size_t)c.y * w32, L, c.y, w, c.w0, c.w1) : 0;
+            int n = c.valid && c.w0 < c.w1 ? flatten_span(fbits + (size_t)c.y * w32, L, c.y, w, w32, c.w0, c.w1) : 0;
             n = row_sum(n);
             if (lane < kRowsPerWave && c.y < h)
                 rowbase[c.y] = n;
@@ -757,7 +792,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
             const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
             const int yy = c.y < h ? c.y : 0;
             const bool ok = c.valid && c.w0 < c.w1;
-            rank_span(fbits + (size_t)yy * w32, L, c.y, w, c.w0, c.w1, lane, ok,
+            rank_span(fbits + (size_t)yy * w32, L, c.y, w, w32, c.w0, c.w1, lane, ok,
                       ok ? rowbase[c.y] : 0);
         }
         return;
