@@ -648,7 +648,7 @@ def test_pipeline_morphology_chains(oracle, h, w):
         rl, rc = oracle.label_batch(m, 8)
         assert np.array_equal(out["mask"], m), chain
         assert np.array_equal(out["labels"], rl) and np.array_equal(out["counts"], rc), chain
-        # without labels the chain takes the non-planting kernels (prefetching stream kernel)
+        # the mask alone (no labelling stage behind the morphology kernels)
         assert np.array_equal(eng.run(img, want=("mask",))["mask"], m), chain
         eng.close()
 

@@ -21,7 +21,7 @@ import sys
 
 STAGE_OF_KERNEL = {
     "bg_mean_u8_fast_kernel": "bg", "bg_mean_u8_kernel": "bg", "gauss_fused_kernel": "gauss_fused", "gauss_mfma_kernel": "gauss_mfma",
-    "morph_fused_kernel": "morph_fused", "morph_stream_kernel": "morph_fused", "morph_stream2_kernel": "morph_fused", "ccl_init_kernel": "ccl_init", "ccl_frame_kernel": "ccl_frame", "ccl_link_kernel": "ccl_link",
+    "morph_fused_kernel": "morph_fused", "morph_stream_kernel": "morph_fused", "ccl_init_kernel": "ccl_init", "ccl_frame_kernel": "ccl_frame", "ccl_link_kernel": "ccl_link",
     "ccl_flatten_kernel": "ccl_flatten", "ccl_rowscan_kernel": "ccl_rowscan",
     "ccl_rank_kernel": "ccl_rank", "ccl_paint_kernel": "ccl_paint",
 }

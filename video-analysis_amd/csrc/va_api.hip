@@ -554,7 +554,7 @@ int va_largest_contour(const uint8_t *mask, int n, int h, int w, int32_t *points
     if (rc)
         return rc;
     rc = launch_ccl(bits, forest, ncomponents, n, h, w, 8, rows, rows_bytes, nullptr, 0, st, nullptr,
-                    false, /*paint=*/false);
+                    /*paint=*/false);
     if (rc)
         return rc;
     return launch_largest_contour(bits, forest, n, h, w, keys, points, max_points, npoints, area, st);
@@ -837,8 +837,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             return rc;
         VA_MARK("threshold_pack");
     }
-    // 4. morphology on bits (one fused LDS kernel when the sequence allows it); when labels are
-    //    wanted the fused kernel also plants the labelling forest
+    // 4. morphology on bits (one fused kernel when the sequence allows it)
     const bool want_ccl = c.connectivity && (labels_out || counts_out || stats_out);
     int32_t *labels = nullptr;
     if (want_ccl) {
@@ -856,16 +855,12 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             labels = p->labels_scratch;
         }
     }
-    bool forest_ready = false;
     if (c.morph_count > 0 && morph_fused_supported(c.width, p->se, c.morph_count)) {
-        // the chip-wide labelling path wants its forest planted by the last morphology op
-        int32_t *plant = ccl_frame_kernel_used(n, c.height, c.width) ? nullptr : labels;
-        rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], plant, n, c.height, c.width, c.morph_op,
-                                p->se, c.morph_count, st);
+        rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], n, c.height, c.width, c.morph_op, p->se,
+                                c.morph_count, st);
         if (rc)
             return rc;
         b ^= 1;
-        forest_ready = plant != nullptr;
         VA_MARK("morph_fused");
     } else {
         for (int i = 0; i < c.morph_count; i++) {
@@ -887,7 +882,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     if (want_ccl) {
         rc = launch_ccl(p->bits[b], labels, counts_out ? counts_out : p->counts_scratch, n,
                         c.height, c.width, c.connectivity, p->ccl_ws, p->ccl_ws_bytes, stats_out,
-                        c.max_labels, st, prof, forest_ready);
+                        c.max_labels, st, prof);
         if (rc)
             return rc;
     }

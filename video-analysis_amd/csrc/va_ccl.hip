@@ -1423,7 +1423,7 @@ size_t ccl_workspace_bytes(int n, int h, int w)
 // workspace here = row_cnt + row_off only (the caller owns the bit mask)
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st, StageProfiler *prof, bool forest_ready, bool paint)
+               hipStream_t st, StageProfiler *prof, bool paint)
 {
 #define VA_MARK(nm)      \
     do {                 \
@@ -1492,7 +1492,7 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
         VA_LAUNCH_CHECK("ccl_frame_kernel");
         VA_MARK("ccl_frame");
     } else {
-        int rc = chip_wide(sgrid_all, all, n, !forest_ready);
+        int rc = chip_wide(sgrid_all, all, n, true);
         if (rc)
             return rc;
     }

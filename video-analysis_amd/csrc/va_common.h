@@ -159,22 +159,22 @@ int launch_image_statistics(const uint8_t *src, double *mean_out, double *var_ou
                             int w, const RowSpans &se, double prior, int exclude_center,
                             hipStream_t st);
 
-// the whole op sequence in one LDS-resident kernel; labels_init != nullptr also plants the
-// labelling forest (then pass forest_ready = true to launch_ccl)
+// the whole op sequence in one kernel (register-streaming for one or two small rectangles,
+// LDS-resident otherwise)
 bool morph_fused_supported(int w, const RowSpans *se, int count);
-int launch_morph_fused(const uint32_t *src, uint32_t *dst, int32_t *labels_init, int n, int h,
+int launch_morph_fused(const uint32_t *src, uint32_t *dst, int n, int h,
                        int w, const int *ops, const RowSpans *se, int count, hipStream_t st);
 
 // connected components on bit masks; labels doubles as the union-find forest
 size_t ccl_workspace_bytes(int n, int h, int w);
-// true: launch_ccl labels with one workgroup per frame (forest in LDS) and needs no planted
-// forest; false: chip-wide multi-pass path (frames taller than the LDS row table, or the test hook)
+// true: launch_ccl labels with one workgroup per frame (forest in LDS); false: chip-wide
+// multi-pass path (large frames, small batches, or the test hook)
 bool ccl_frame_kernel_used(int n, int h, int w);
 void ccl_test_hook(int path, int lds_runs);   // see va_test_hook_labelling
 size_t ccl_rows_workspace_bytes(int n, int h);   // launch_ccl's workspace (the caller owns the bit mask)
 int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st, StageProfiler *prof = nullptr, bool forest_ready = false,
+               hipStream_t st, StageProfiler *prof = nullptr,
                bool paint = true);
 // outer contour of the component with the largest contour area (8-connectivity), on a forest
 // prepared by launch_ccl(..., paint = false): roots hold -(label) at their first pixel

@@ -168,9 +168,7 @@ morph_bits_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, 
 // ------------------------------------------------------------------ fused op sequence on bits
 // The pipeline's whole morphology chain (e.g. 5x5 dilate then 5x5 erode) in one kernel: a block
 // owns a band of kBandRows rows of one frame, stages the band plus the chain's total vertical
-// reach in LDS and applies the ops LDS -> LDS; only the final band is written.  Optionally the
-// last op also plants the union-find forest of the labelling stage (every run's first pixel
-// points at itself), which saves that stage a pass over the mask.
+// reach in LDS and applies the ops LDS -> LDS; only the final band is written.
 struct MorphSeq {
     int count;
     int reach_total;            // sum over ops of max(anchor, ksize-1-anchor)
@@ -230,8 +228,7 @@ __device__ __forceinline__ uint32_t shift_words(uint32_t l, uint32_t c, uint32_t
 
 // thread layout: 64 word columns x 4 rows; loops stride over rows / column chunks (no div/mod)
 __global__ void __launch_bounds__(kBlock)
-morph_fused_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
-                   int32_t *__restrict__ labels, int h, int w, int w32, int nbands, MorphSeq seq)
+morph_fused_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int h, int w, int w32, int nbands, MorphSeq seq)
 {
     extern __shared__ uint32_t s_rows[];   // 3 x (kBandRows + 2*reach_total) x w32
     const int band = blockIdx.x % nbands, f = blockIdx.x / nbands;
@@ -326,26 +323,13 @@ morph_fused_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
         bufB = t;
     }
 
-    // write the band (+ plant the labelling forest)
+    // write the band
     const int yend = min(h, y0 + kBandRows);
     uint32_t *fdst = dst + (size_t)f * h * w32;
-    int32_t *L = labels ? labels + (size_t)f * h * w : nullptr;
     for (int y = y0 + ty; y < yend; y += 4) {
         const uint32_t *row = bufA + (y - rbase) * w32;
-        for (int wi = tx; wi < w32; wi += 64) {
-            const uint32_t m = row[wi];
-            fdst[(size_t)y * w32 + wi] = m;
-            if (L) {
-                const uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
-                uint32_t st = m & ~((m << 1) | prev);
-                while (st) {
-                    const int bpos = __ffs(st) - 1;
-                    st &= st - 1;
-                    const int idx = y * w + (wi << 5) + bpos;
-                    L[idx] = idx;
-                }
-            }
-        }
+        for (int wi = tx; wi < w32; wi += 64)
+            fdst[(size_t)y * w32 + wi] = row[wi];
     }
 }
 
@@ -356,8 +340,8 @@ morph_fused_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
 // over a k-row register window.  Erosion is dilation of the complement (pixels outside the frame
 // are 0 in both pictures, which is exactly OpenCV's "outside never wins" border), so every op is
 // an OR-dilation between runtime complement masks.  The second op takes its left/right
-// neighbour words from the adjacent lanes, which costs one halo lane per side: a wave stores 62
-// word columns (64 for a single op).  Optionally plants the labelling forest like the LDS kernel.
+// neighbour words from the adjacent lanes, which costs halo lanes on either side: a wave stores 60
+// word columns (62 for a single op).
 constexpr int kStreamBand = 32;
 
 template <int K>
@@ -372,128 +356,9 @@ __device__ __forceinline__ uint32_t hdilate(uint32_t l, uint32_t c, uint32_t r)
     return acc;
 }
 
-template <int K0, int K1>
-__global__ void __launch_bounds__(kBlock)
-morph_stream_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
-                    int32_t *__restrict__ labels, int n, int h, int w, int w32, int nbands,
-                    int nchunks, uint32_t flip_in, uint32_t flip_mid, uint32_t flip_out)
-{
-    constexpr int A0 = K0 / 2, A1 = K1 / 2;
-    // lanes [LO, LO+COLS) store; the lanes left of them only supply neighbours: one so that the
-    // forest planting sees the previous word's final msb, one more (and one on the right) for
-    // the second op's left/right input words
-    constexpr int LO = K1 ? 2 : 1;
-    constexpr int COLS = K1 ? 60 : 63;
-    const int lane = threadIdx.x & 63;
-    size_t item = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // (frame, band, chunk)
-    const int chunk = (int)(item % nchunks);
-    item /= nchunks;
-    const int band = (int)(item % nbands);
-    const size_t f = item / nbands;
-    const int wi = chunk * COLS + lane - LO;             // this lane's word column
-    const bool col_in = wi >= 0 && wi < w32;
-    const bool col_store = col_in && lane >= LO && lane < LO + COLS;
-    const int tail = w & 31;
-    const uint32_t valid = !col_in ? 0u : (wi == w32 - 1 && tail ? (0xFFFFFFFFu >> (32 - tail)) : 0xFFFFFFFFu);
-    const uint32_t valid_l = (wi - 1 >= 0 && wi - 1 < w32) ? 0xFFFFFFFFu : 0u;   // never the tail word
-    const uint32_t valid_r = !(wi + 1 >= 0 && wi + 1 < w32) ? 0u
-                             : (wi + 1 == w32 - 1 && tail ? (0xFFFFFFFFu >> (32 - tail)) : 0xFFFFFFFFu);
-    const uint32_t *fsrc = src + f * (size_t)h * w32;
-    uint32_t *fdst = dst + f * (size_t)h * w32;
-    int32_t *L = labels ? labels + f * (size_t)h * w : nullptr;
-    if (f >= (size_t)n)
-        return;   // surplus waves of the last block (wave-uniform)
-
-    const int y0 = band * kStreamBand;
-    if (y0 >= h)
-        return;
-    const int y_first = y0 - A0 - A1;                       // first input row marched
-    const int y_last = min(h, y0 + kStreamBand) - 1 + A0 + A1;
-
-    auto load3 = [&](int y, uint32_t &l, uint32_t &c, uint32_t &r) {
-        l = c = r = 0u;
-        if (y >= 0 && y < h) {
-            const uint32_t *row = fsrc + (size_t)y * w32;
-            if (valid)
-                c = (row[wi] ^ flip_in) & valid;
-            if (valid_l)
-                l = (row[wi - 1] ^ flip_in) & valid_l;
-            if (valid_r)
-                r = (row[wi + 1] ^ flip_in) & valid_r;
-        }
-    };
-
-    uint32_t win0[K0], win1[K1 ? K1 : 1];
-#pragma unroll
-    for (int k = 0; k < K0; k++)
-        win0[k] = 0u;
-#pragma unroll
-    for (int k = 0; k < (K1 ? K1 : 1); k++)
-        win1[k] = 0u;
-
-    uint32_t nl, nc, nr;
-    load3(y_first, nl, nc, nr);
-    for (int y = y_first; y <= y_last; y++) {
-        const uint32_t l = nl, c = nc, r = nr;
-        if (y < y_last)
-            load3(y + 1, nl, nc, nr);             // prefetch the next row behind this row's ALU work
-        // ---- op 0: horizontal pass of input row y, vertical window -> row y - A0
-#pragma unroll
-        for (int k = 0; k + 1 < K0; k++)
-            win0[k] = win0[k + 1];
-        win0[K0 - 1] = hdilate<K0>(l, c, r);
-        uint32_t v0 = 0u;
-#pragma unroll
-        for (int k = 0; k < K0; k++)
-            v0 |= win0[k];
-        const int ya = y - A0;                    // row of v0
-        uint32_t out;
-        int yo;
-        if constexpr (K1 == 0) {
-            out = (v0 ^ flip_out) & valid;
-            yo = ya;
-        } else {
-            // input of op 1: rows outside the frame contribute nothing
-            uint32_t t = (ya >= 0 && ya < h) ? ((v0 ^ flip_mid) & valid) : 0u;
-            uint32_t tl = __shfl_up(t, 1, 64), tr = __shfl_down(t, 1, 64);
-            if (lane == 0)
-                tl = 0u;
-            if (lane == 63)
-                tr = 0u;
-#pragma unroll
-            for (int k = 0; k + 1 < K1; k++)
-                win1[k] = win1[k + 1];
-            win1[K1 ? K1 - 1 : 0] = hdilate<(K1 ? K1 : 1)>(tl, t, tr);
-            uint32_t v1 = 0u;
-#pragma unroll
-            for (int k = 0; k < K1; k++)
-                v1 |= win1[k];
-            out = (v1 ^ flip_out) & valid;
-            yo = ya - A1;
-        }
-        if (yo >= y0 && yo < y0 + kStreamBand && yo < h) {
-            // the forest needs the msb of the previous word's FINAL value
-            const uint32_t pw = __shfl_up(out, 1, 64);
-            if (col_store) {
-                fdst[(size_t)yo * w32 + wi] = out;
-                if (L) {
-                    const uint32_t prev = wi > 0 ? pw >> 31 : 0u;
-                    uint32_t st = out & ~((out << 1) | prev);
-                    while (st) {
-                        const int bpos = __ffs(st) - 1;
-                        st &= st - 1;
-                        const int idx = yo * w + (wi << 5) + bpos;
-                        L[idx] = idx;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// The same chains without forest planting (the per-frame labelling kernel needs none): one load per
-// row and lane -- the left/right words come from the neighbouring lanes by DPP wave shifts -- and
-// eight rows of loads in flight (a row-by-row march pays one memory round trip per row).
+// One load per row and lane -- the left/right words come from the neighbouring lanes by DPP wave
+// shifts -- and eight rows of loads in flight (a row-by-row march pays one memory round trip per
+// row: 0.081 against 0.036 ms for the benchmark's closing).
 constexpr int kStreamGroup = 8;
 
 __device__ __forceinline__ uint32_t lane_left(uint32_t v)    // value of lane - 1 (0 into lane 0)
@@ -507,7 +372,7 @@ __device__ __forceinline__ uint32_t lane_right(uint32_t v)   // value of lane + 
 
 template <int K0, int K1>
 __global__ void __launch_bounds__(kBlock)
-morph_stream2_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int n, int h, int w,
+morph_stream_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int n, int h, int w,
                      int w32, int nbands, int nchunks, uint32_t flip_in, uint32_t flip_mid,
                      uint32_t flip_out)
 {
@@ -707,11 +572,11 @@ static bool is_rect_odd(const RowSpans &se, int kmax)
 }
 
 template <int K0, int K1>
-static int launch_stream(const uint32_t *src, uint32_t *dst, int32_t *labels_init, int n, int h,
-                         int w, const int *ops, hipStream_t st)
+static int launch_stream(const uint32_t *src, uint32_t *dst, int n, int h, int w, const int *ops,
+                         hipStream_t st)
 {
     const int w32 = words_per_row(w);
-    const int cols = K1 ? 60 : (labels_init ? 63 : 62);
+    const int cols = K1 ? 60 : 62;
     const int nchunks = cdiv(w32, cols), nbands = cdiv(h, kStreamBand);
     const size_t items = (size_t)n * nbands * nchunks;
     // erode = complement . dilate . complement; adjacent complements cancel
@@ -721,18 +586,14 @@ static int launch_stream(const uint32_t *src, uint32_t *dst, int32_t *labels_ini
     // the grid is rounded up to whole blocks: surplus waves see y0 >= h via the band index
     const int waves_per_block = kBlock / 64;
     const size_t blocks = (items + waves_per_block - 1) / waves_per_block;
-    if (labels_init)
-        morph_stream_kernel<K0, K1><<<(unsigned)blocks, kBlock, 0, st>>>(
-            src, dst, labels_init, n, h, w, w32, nbands, nchunks, flip_in, flip_mid, flip_out);
-    else
-        morph_stream2_kernel<K0, K1><<<(unsigned)blocks, kBlock, 0, st>>>(
-            src, dst, n, h, w, w32, nbands, nchunks, flip_in, flip_mid, flip_out);
+    morph_stream_kernel<K0, K1><<<(unsigned)blocks, kBlock, 0, st>>>(
+        src, dst, n, h, w, w32, nbands, nchunks, flip_in, flip_mid, flip_out);
     VA_LAUNCH_CHECK("morph_stream_kernel");
     return VA_OK;
 }
 
-int launch_morph_fused(const uint32_t *src, uint32_t *dst, int32_t *labels_init, int n, int h,
-                       int w, const int *ops, const RowSpans *se, int count, hipStream_t st)
+int launch_morph_fused(const uint32_t *src, uint32_t *dst, int n, int h, int w, const int *ops,
+                       const RowSpans *se, int count, hipStream_t st)
 {
     VA_REQUIRE(morph_fused_supported(w, se, count), "fused morphology: unsupported sequence");
     if (n == 0 || h == 0 || w == 0)
@@ -741,7 +602,7 @@ int launch_morph_fused(const uint32_t *src, uint32_t *dst, int32_t *labels_init,
         const int k0 = se[0].ksize, k1 = count == 2 ? se[1].ksize : 0;
 #define VA_STREAM_CASE(A, B) \
     if (k0 == A && k1 == B)  \
-        return launch_stream<A, B>(src, dst, labels_init, n, h, w, ops, st);
+        return launch_stream<A, B>(src, dst, n, h, w, ops, st);
         VA_STREAM_CASE(3, 0) VA_STREAM_CASE(5, 0) VA_STREAM_CASE(7, 0)
         VA_STREAM_CASE(3, 3) VA_STREAM_CASE(3, 5) VA_STREAM_CASE(3, 7)
         VA_STREAM_CASE(5, 3) VA_STREAM_CASE(5, 5) VA_STREAM_CASE(5, 7)
@@ -760,7 +621,7 @@ int launch_morph_fused(const uint32_t *src, uint32_t *dst, int32_t *labels_init,
     const int w32 = words_per_row(w);
     const int nbands = cdiv(h, kBandRows);
     const size_t lds = 3 * (size_t)(kBandRows + 2 * seq.reach_total) * w32 * sizeof(uint32_t);
-    morph_fused_kernel<<<nbands * n, kBlock, lds, st>>>(src, dst, labels_init, h, w, w32, nbands,
+    morph_fused_kernel<<<nbands * n, kBlock, lds, st>>>(src, dst, h, w, w32, nbands,
                                                        seq);
     VA_LAUNCH_CHECK("morph_fused_kernel");
     return VA_OK;
