@@ -81,6 +81,19 @@ def test_gaussian_u8_single_launch_kernels(ops, oracle, shape, sigma):
         assert np.array_equal(ops.gaussian_blur(c, sigma), c)
 
 
+@pytest.mark.parametrize("shape,sigma", [((2, 48, 64, 3), 2.0), ((1, 33, 112, 3), 5.0), ((3, 40, 80, 2), 1.0),
+                                         ((1, 64, 96, 4), 3.3), ((1, 35, 1936, 3), 4.0)])
+def test_gaussian_u8_colour_planes(ops, oracle, shape, sigma):
+    """colour frames the matrix-core kernel takes as n * c single-channel planes (w % 16 == 0):
+    every channel is filtered on its own, exactly like the oracle's per-channel definition"""
+    rng = np.random.default_rng(shape[2] + shape[3])
+    im = rng.integers(0, 256, shape, dtype=np.uint8)
+    im[0, :4] = 255
+    ref = oracle.gaussian_u8(im, sigma)
+    assert np.array_equal(ops.gaussian_blur(im, sigma, color=True), ref)
+    assert np.array_equal(ops.gaussian_blur(im, sigma, color=True, implementation="generic"), ref)
+
+
 def test_gaussian_u8_extremes_and_color(ops, oracle):
     for v in (0, 255, 77):
         c = np.full((2, 50, 70), v, np.uint8)

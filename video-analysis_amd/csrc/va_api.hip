@@ -270,6 +270,23 @@ int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
             return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
     }
     void *scratch;
+    if (c >= 2 && c <= 4 && gauss_mfma_supported(w, h, t) && reinterpret_cast<uintptr_t>(src) % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(dst) % 4 == 0) {
+        // colour frames: every channel is an independent single-channel blur (OpenCV filters
+        // the channels separately), so they go through the matrix-core kernel as n * c planes
+        const size_t px = (size_t)h * w, plane_bytes = (size_t)n * c * px;   // px % 16 == 0 here
+        rc = get_scratch(2 * plane_bytes, &scratch);
+        if (rc)
+            return rc;
+        uint8_t *pin = (uint8_t *)scratch, *pout = pin + plane_bytes;        // both 16-byte aligned
+        rc = launch_channel_planes(src, pin, n, px, c, true, as_stream(stream));
+        if (rc)
+            return rc;
+        rc = launch_gauss_mfma_u8(pin, pout, nullptr, -1, n * c, h, w, t, as_stream(stream));
+        if (rc)
+            return rc;
+        return launch_channel_planes(pout, dst, n, px, c, false, as_stream(stream));
+    }
     rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);
     if (rc)
         return rc;

@@ -521,6 +521,74 @@ int launch_mono_mean(const uint8_t *src, uint8_t *dst, size_t pixels, hipStream_
     return VA_OK;
 }
 
+// ---- interleaved channels <-> planes (colour frames through the single-channel Gaussian) -----
+// planes are laid out (frame, channel, h, w): every plane is a single-channel frame of its own
+template <int C, bool SPLIT>
+__global__ void __launch_bounds__(kBlock)
+channel_planes_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t px,
+                      size_t quads_per_frame, size_t total_quads)
+{
+    // thread = 4 consecutive pixels of one frame (px % 4 == 0): 4 C interleaved bytes <-> one
+    // dword in each of the C planes
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= total_quads)
+        return;
+    const size_t f = t / quads_per_frame, q = t % quads_per_frame;
+    const uint8_t *inter = (SPLIT ? src : dst) + (f * px + q * 4) * C;
+    uint8_t b[4 * C];
+    if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < C; i++)
+            *reinterpret_cast<uint32_t *>(b + 4 * i) = *reinterpret_cast<const uint32_t *>(inter + 4 * i);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t v = b[c] | (b[C + c] << 8) | (b[2 * C + c] << 16) | ((uint32_t)b[3 * C + c] << 24);
+            *reinterpret_cast<uint32_t *>(dst + (f * C + c) * px + q * 4) = v;
+        }
+    } else {
+        uint8_t p[C][4];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            *reinterpret_cast<uint32_t *>(p[c]) = *reinterpret_cast<const uint32_t *>(src + (f * C + c) * px + q * 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                b[i * C + c] = p[c][i];
+        uint8_t *o = dst + (f * px + q * 4) * C;
+#pragma unroll
+        for (int i = 0; i < C; i++)
+            *reinterpret_cast<uint32_t *>(o + 4 * i) = *reinterpret_cast<const uint32_t *>(b + 4 * i);
+    }
+}
+
+// split == true: (n, px, c) interleaved -> (n, c, px) planes; false: the way back
+int launch_channel_planes(const uint8_t *src, uint8_t *dst, int n, size_t px, int c, bool split,
+                          hipStream_t st)
+{
+    VA_REQUIRE(src && dst && px % 4 == 0 && c >= 2 && c <= 4, "channel planes: bad arguments");
+    if (n == 0)
+        return VA_OK;
+    const size_t qpf = px / 4, total = qpf * n;
+    const unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
+#define VA_CP(CC)                                                                                   \
+    do {                                                                                            \
+        if (split)                                                                                  \
+            channel_planes_kernel<CC, true><<<grid, kBlock, 0, st>>>(src, dst, px, qpf, total);     \
+        else                                                                                        \
+            channel_planes_kernel<CC, false><<<grid, kBlock, 0, st>>>(src, dst, px, qpf, total);    \
+    } while (0)
+    if (c == 2)
+        VA_CP(2);
+    else if (c == 3)
+        VA_CP(3);
+    else
+        VA_CP(4);
+#undef VA_CP
+    VA_LAUNCH_CHECK("channel_planes_kernel");
+    return VA_OK;
+}
+
 // ---- np.rot90 (FilterRotate, video/filters.py:341) --------------------------------------------
 // Pixels are opaque E-byte elements (channels x dtype).  A 32 x 32 tile goes through LDS so that
 // both the reads and the writes of a wave are rows of consecutive elements, whatever the turn.
