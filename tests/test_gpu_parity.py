@@ -82,16 +82,21 @@ def test_gaussian_u8_single_launch_kernels(ops, oracle, shape, sigma):
 
 
 @pytest.mark.parametrize("shape,sigma", [((2, 48, 64, 3), 2.0), ((1, 33, 112, 3), 5.0), ((3, 40, 80, 2), 1.0),
-                                         ((1, 64, 96, 4), 3.3), ((1, 35, 1936, 3), 4.0)])
-def test_gaussian_u8_colour_planes(ops, oracle, shape, sigma):
-    """colour frames the matrix-core kernel takes as n * c single-channel planes (w % 16 == 0):
-    every channel is filtered on its own, exactly like the oracle's per-channel definition"""
-    rng = np.random.default_rng(shape[2] + shape[3])
+                                         ((1, 64, 96, 4), 3.3), ((1, 35, 1936, 3), 4.0),
+                                         ((2, 40, 67), 5.3), ((1, 33, 1918), 5.0), ((2, 50, 101, 3), 2.0),
+                                         ((1, 64, 49), 5.0), ((1, 32, 33, 4), 5.3)])
+def test_gaussian_u8_planes_path(ops, oracle, shape, sigma):
+    """frames the matrix-core kernel takes after a re-layout into single-channel planes: colour
+    frames (every channel filtered on its own) and widths that are no multiple of 16 (planes padded
+    with the reflected continuation of each row)"""
+    color = len(shape) == 4
+    rng = np.random.default_rng(sum(shape))
     im = rng.integers(0, 256, shape, dtype=np.uint8)
     im[0, :4] = 255
+    im[..., -3:, :] = 255 if not color else im[..., -3:, :]
     ref = oracle.gaussian_u8(im, sigma)
-    assert np.array_equal(ops.gaussian_blur(im, sigma, color=True), ref)
-    assert np.array_equal(ops.gaussian_blur(im, sigma, color=True, implementation="generic"), ref)
+    assert np.array_equal(ops.gaussian_blur(im, sigma, color=color), ref)
+    assert np.array_equal(ops.gaussian_blur(im, sigma, color=color, implementation="generic"), ref)
 
 
 def test_gaussian_u8_extremes_and_color(ops, oracle):

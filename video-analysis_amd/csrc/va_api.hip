@@ -270,22 +270,27 @@ int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
             return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
     }
     void *scratch;
-    if (c >= 2 && c <= 4 && gauss_mfma_supported(w, h, t) && reinterpret_cast<uintptr_t>(src) % 4 == 0 &&
-        reinterpret_cast<uintptr_t>(dst) % 4 == 0) {
-        // colour frames: every channel is an independent single-channel blur (OpenCV filters
-        // the channels separately), so they go through the matrix-core kernel as n * c planes
-        const size_t px = (size_t)h * w, plane_bytes = (size_t)n * c * px;   // px % 16 == 0 here
-        rc = get_scratch(2 * plane_bytes, &scratch);
-        if (rc)
-            return rc;
-        uint8_t *pin = (uint8_t *)scratch, *pout = pin + plane_bytes;        // both 16-byte aligned
-        rc = launch_channel_planes(src, pin, n, px, c, true, as_stream(stream));
-        if (rc)
-            return rc;
-        rc = launch_gauss_mfma_u8(pin, pout, nullptr, -1, n * c, h, w, t, as_stream(stream));
-        if (rc)
-            return rc;
-        return launch_channel_planes(pout, dst, n, px, c, false, as_stream(stream));
+    {
+        // Everything else the matrix-core kernel can take after a re-layout: colour frames (the
+        // channels are filtered independently, as OpenCV does) and widths that are not a multiple
+        // of 16 go through planes (frame, channel, h, wp).  A plane that is wider than the frame
+        // carries the reflected continuation of every row over at least the kernel's radius, so
+        // the blur of the plane is the blur of the frame on the first w columns.
+        const int wp = (w % 16 == 0) ? w : ((w + 16 + 15) / 16) * 16;
+        if (c <= 4 && (c > 1 || wp != w) && wp - w < w && gauss_mfma_supported(wp, h, t)) {
+            const size_t plane_bytes = (size_t)n * c * h * wp;               // multiple of 16
+            rc = get_scratch(2 * plane_bytes, &scratch);
+            if (rc)
+                return rc;
+            uint8_t *pin = (uint8_t *)scratch, *pout = pin + plane_bytes;    // both 16-byte aligned
+            rc = launch_channel_planes(src, pin, n, h, w, wp, c, true, as_stream(stream));
+            if (rc)
+                return rc;
+            rc = launch_gauss_mfma_u8(pin, pout, nullptr, -1, n * c, h, wp, t, as_stream(stream));
+            if (rc)
+                return rc;
+            return launch_channel_planes(pout, dst, n, h, w, wp, c, false, as_stream(stream));
+        }
     }
     rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);
     if (rc)

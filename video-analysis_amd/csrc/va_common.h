@@ -125,9 +125,9 @@ int launch_threshold_u8(const uint8_t *src, uint8_t *dst, size_t count, int thre
 int launch_time_difference(const uint8_t *a, const uint8_t *b, int16_t *out, size_t count,
                            hipStream_t st);
 int launch_mono_mean(const uint8_t *src, uint8_t *dst, size_t pixels, hipStream_t st);
-// (n, px, c) interleaved u8 <-> (n, c, px) planes, c = 2..4, px % 4 == 0
-int launch_channel_planes(const uint8_t *src, uint8_t *dst, int n, size_t px, int c, bool split,
-                          hipStream_t st);
+// (n, h, w, c) interleaved u8 <-> (n, c, h, wp) planes padded to wp columns by reflection
+int launch_channel_planes(const uint8_t *src, uint8_t *dst, int n, int h, int w, int wp, int c,
+                          bool split, hipStream_t st);
 // np.rot90(frame, k) on (N,H,W) frames of opaque elem_bytes-byte pixels
 int launch_rot90(const void *src, void *dst, int n, int h, int w, int elem_bytes, int k,
                  hipStream_t st);

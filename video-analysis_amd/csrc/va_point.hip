@@ -521,64 +521,75 @@ int launch_mono_mean(const uint8_t *src, uint8_t *dst, size_t pixels, hipStream_
     return VA_OK;
 }
 
-// ---- interleaved channels <-> planes (colour frames through the single-channel Gaussian) -----
-// planes are laid out (frame, channel, h, w): every plane is a single-channel frame of its own
+// ---- interleaved channels <-> planes (any frame through the single-channel Gaussian) ---------
+// planes are laid out (frame, channel, h, wp): every plane is a single-channel frame of its own,
+// wp >= w columns wide.  Columns w .. wp-1 hold the BORDER_REFLECT_101 continuation of the row, so
+// a blur of the plane equals the blur of the original row wherever its window stays left of wp.
 template <int C, bool SPLIT>
 __global__ void __launch_bounds__(kBlock)
-channel_planes_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t px,
-                      size_t quads_per_frame, size_t total_quads)
+channel_planes_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w, int wp,
+                      size_t total_quads)
 {
-    // thread = 4 consecutive pixels of one frame (px % 4 == 0): 4 C interleaved bytes <-> one
-    // dword in each of the C planes
+    // thread = 4 consecutive plane columns of one row of one frame (wp % 4 == 0)
     const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= total_quads)
         return;
-    const size_t f = t / quads_per_frame, q = t % quads_per_frame;
-    const uint8_t *inter = (SPLIT ? src : dst) + (f * px + q * 4) * C;
-    uint8_t b[4 * C];
+    const int qpr = wp / 4;
+    const int xq = (int)(t % qpr) * 4;
+    const size_t rowi = t / qpr;                 // f * h + y
+    const size_t f = rowi / h, y = rowi % h;
+    const uint8_t *inter_c = (SPLIT ? src : nullptr);
+    uint8_t *inter = SPLIT ? nullptr : dst;
+    const size_t inter_row = rowi * (size_t)w * C;
     if (SPLIT) {
 #pragma unroll
-        for (int i = 0; i < C; i++)
-            *reinterpret_cast<uint32_t *>(b + 4 * i) = *reinterpret_cast<const uint32_t *>(inter + 4 * i);
-#pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t v = b[c] | (b[C + c] << 8) | (b[2 * C + c] << 16) | ((uint32_t)b[3 * C + c] << 24);
-            *reinterpret_cast<uint32_t *>(dst + (f * C + c) * px + q * 4) = v;
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int x = xq + i;
+                x = x < w ? x : 2 * (w - 1) - x;     // reflected continuation (wp - w < w)
+                x = max(x, 0);
+                v |= (uint32_t)inter_c[inter_row + (size_t)x * C + c] << (8 * i);
+            }
+            *reinterpret_cast<uint32_t *>(dst + ((f * C + c) * h + y) * (size_t)wp + xq) = v;
         }
     } else {
         uint8_t p[C][4];
 #pragma unroll
         for (int c = 0; c < C; c++)
-            *reinterpret_cast<uint32_t *>(p[c]) = *reinterpret_cast<const uint32_t *>(src + (f * C + c) * px + q * 4);
+            *reinterpret_cast<uint32_t *>(p[c]) =
+                *reinterpret_cast<const uint32_t *>(src + ((f * C + c) * h + y) * (size_t)wp + xq);
 #pragma unroll
         for (int i = 0; i < 4; i++)
+            if (xq + i < w) {
 #pragma unroll
-            for (int c = 0; c < C; c++)
-                b[i * C + c] = p[c][i];
-        uint8_t *o = dst + (f * px + q * 4) * C;
-#pragma unroll
-        for (int i = 0; i < C; i++)
-            *reinterpret_cast<uint32_t *>(o + 4 * i) = *reinterpret_cast<const uint32_t *>(b + 4 * i);
+                for (int c = 0; c < C; c++)
+                    inter[inter_row + (size_t)(xq + i) * C + c] = p[c][i];
+            }
     }
 }
 
-// split == true: (n, px, c) interleaved -> (n, c, px) planes; false: the way back
-int launch_channel_planes(const uint8_t *src, uint8_t *dst, int n, size_t px, int c, bool split,
-                          hipStream_t st)
+// split == true: (n, h, w, c) interleaved -> (n, c, h, wp) planes; false: the way back (crop to w)
+int launch_channel_planes(const uint8_t *src, uint8_t *dst, int n, int h, int w, int wp, int c,
+                          bool split, hipStream_t st)
 {
-    VA_REQUIRE(src && dst && px % 4 == 0 && c >= 2 && c <= 4, "channel planes: bad arguments");
+    VA_REQUIRE(src && dst && wp % 4 == 0 && wp >= w && wp - w < w && c >= 1 && c <= 4,
+               "channel planes: bad arguments");
     if (n == 0)
         return VA_OK;
-    const size_t qpf = px / 4, total = qpf * n;
+    const size_t total = (size_t)n * h * (wp / 4);
     const unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
 #define VA_CP(CC)                                                                                   \
     do {                                                                                            \
         if (split)                                                                                  \
-            channel_planes_kernel<CC, true><<<grid, kBlock, 0, st>>>(src, dst, px, qpf, total);     \
+            channel_planes_kernel<CC, true><<<grid, kBlock, 0, st>>>(src, dst, h, w, wp, total);    \
         else                                                                                        \
-            channel_planes_kernel<CC, false><<<grid, kBlock, 0, st>>>(src, dst, px, qpf, total);    \
+            channel_planes_kernel<CC, false><<<grid, kBlock, 0, st>>>(src, dst, h, w, wp, total);   \
     } while (0)
-    if (c == 2)
+    if (c == 1)
+        VA_CP(1);
+    else if (c == 2)
         VA_CP(2);
     else if (c == 3)
         VA_CP(3);
