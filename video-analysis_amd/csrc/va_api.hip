@@ -65,7 +65,8 @@ struct va_pipeline {
     double *bg_recip;  // per-frame reciprocals of the running mean's divisor
     void *diff;        // background-subtracted frames (cfg.dtype)
     void *blur;        // blurred frames when the caller does not ask for them (generic path)
-    void *gscratch;    // generic Gaussian scratch (u16 / f32)
+    void *gscratch;    // generic Gaussian scratch (u16 / f32) or the planes of the re-laid-out u8 blur
+    int planes_wp;     // > 0: u8 blur through reflected-padded single-channel planes of this width
     uint32_t *bits[2];
     void *ccl_ws;
     size_t ccl_ws_bytes;
@@ -252,6 +253,34 @@ int va_gauss_taps_f32(double sigma, int *ksize_out, float *taps_out, int capacit
     return VA_OK;
 }
 
+// Frames the matrix-core Gaussian can take after a re-layout: colour frames (the channels are
+// filtered independently, as OpenCV does) and widths that are not a multiple of 16 go through
+// planes (frame, channel, h, wp).  A plane that is wider than the frame carries the reflected
+// continuation of every row over at least the kernel's radius, so the blur of the plane is the
+// blur of the frame on the first w columns.  Returns the plane width, or 0 when this path does
+// not apply.
+static int planes_width(int h, int w, int c, const TapsQ8 &t)
+{
+    const int wp = (w % 16 == 0) ? w : ((w + 16 + 15) / 16) * 16;
+    if (c >= 1 && c <= 4 && wp - w < w && gauss_mfma_supported(wp, h, t))
+        return wp;
+    return 0;
+}
+static size_t planes_scratch_bytes(int n, int h, int wp, int c) { return 2 * (size_t)n * c * h * wp; }
+static int blur_u8_planes(const uint8_t *src, uint8_t *dst, int n, int h, int w, int wp, int c,
+                          const TapsQ8 &t, void *scratch, hipStream_t st)
+{
+    const size_t plane_bytes = (size_t)n * c * h * wp;                   // multiple of 16
+    uint8_t *pin = (uint8_t *)scratch, *pout = pin + plane_bytes;        // both 16-byte aligned
+    int rc = launch_channel_planes(src, pin, n, h, w, wp, c, true, st);
+    if (rc)
+        return rc;
+    rc = launch_gauss_mfma_u8(pin, pout, nullptr, -1, n * c, h, wp, t, st);
+    if (rc)
+        return rc;
+    return launch_channel_planes(pout, dst, n, h, w, wp, c, false, st);
+}
+
 int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma,
                    void *stream)
 {
@@ -270,27 +299,11 @@ int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
             return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
     }
     void *scratch;
-    {
-        // Everything else the matrix-core kernel can take after a re-layout: colour frames (the
-        // channels are filtered independently, as OpenCV does) and widths that are not a multiple
-        // of 16 go through planes (frame, channel, h, wp).  A plane that is wider than the frame
-        // carries the reflected continuation of every row over at least the kernel's radius, so
-        // the blur of the plane is the blur of the frame on the first w columns.
-        const int wp = (w % 16 == 0) ? w : ((w + 16 + 15) / 16) * 16;
-        if (c <= 4 && (c > 1 || wp != w) && wp - w < w && gauss_mfma_supported(wp, h, t)) {
-            const size_t plane_bytes = (size_t)n * c * h * wp;               // multiple of 16
-            rc = get_scratch(2 * plane_bytes, &scratch);
-            if (rc)
-                return rc;
-            uint8_t *pin = (uint8_t *)scratch, *pout = pin + plane_bytes;    // both 16-byte aligned
-            rc = launch_channel_planes(src, pin, n, h, w, wp, c, true, as_stream(stream));
-            if (rc)
-                return rc;
-            rc = launch_gauss_mfma_u8(pin, pout, nullptr, -1, n * c, h, wp, t, as_stream(stream));
-            if (rc)
-                return rc;
-            return launch_channel_planes(pout, dst, n, h, w, wp, c, false, as_stream(stream));
-        }
+    if (const int wp = planes_width(h, w, c, t)) {
+        rc = get_scratch(planes_scratch_bytes(n, h, wp, c), &scratch);
+        if (rc)
+            return rc;
+        return blur_u8_planes(src, dst, n, h, w, wp, c, t, scratch, as_stream(stream));
     }
     rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);
     if (rc)
@@ -699,7 +712,13 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
             PIPE_MALLOC(p->bg_recip, bg_scratch_bytes(cfg->max_batch));
     }
     if (cfg->sigma > 0 && !p->fused) {
-        PIPE_MALLOC(p->gscratch, nb * p->px * (cfg->dtype == VA_U8 ? 2 : 4));
+        size_t gs = nb * p->px * (cfg->dtype == VA_U8 ? 2 : 4);
+        if (cfg->dtype == VA_U8) {
+            p->planes_wp = planes_width(cfg->height, cfg->width, cfg->channels, p->tq);
+            if (p->planes_wp)
+                gs = planes_scratch_bytes(cfg->max_batch, cfg->height, p->planes_wp, cfg->channels);
+        }
+        PIPE_MALLOC(p->gscratch, gs);
         PIPE_MALLOC(p->blur, nb * p->px * esz);
     }
     if (masks) {
@@ -717,8 +736,8 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
              cfg->sigma > 0 ? (p->fused ? (p->mfma ? "mfma-i8" : "fused-lds")
                                         : (cfg->dtype == VA_F32 &&
                                                    gauss_f32_fast_supported(cfg->width, cfg->channels, p->tf)
-                                               ? "f32-lds-row+ring-col"
-                                               : "generic"))
+                                               ? "f32-packed"
+                                               : (p->planes_wp ? "mfma-i8-planes" : "generic")))
                             : "none",
              cfg->sigma > 0 ? (cfg->dtype == VA_U8 ? p->tq.ksize : p->tf.ksize) : 0, cfg->thresh,
              cfg->morph_count, cfg->connectivity);
@@ -828,7 +847,10 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             VA_MARK(p->mfma ? "gauss_mfma" : "gauss_fused");
         } else {
             void *dst = filtered_out ? filtered_out : p->blur;
-            if (c.dtype == VA_U8)
+            if (c.dtype == VA_U8 && p->planes_wp)
+                rc = blur_u8_planes((const uint8_t *)cur, (uint8_t *)dst, n, c.height, c.width,
+                                    p->planes_wp, c.channels, p->tq, p->gscratch, st);
+            else if (c.dtype == VA_U8)
                 rc = launch_gauss_generic_u8((const uint8_t *)cur, (uint8_t *)dst,
                                              (uint16_t *)p->gscratch, n, c.height, c.width,
                                              c.channels, p->tq, st);
@@ -842,7 +864,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             if (rc)
                 return rc;
             cur = dst;
-            VA_MARK("gauss_generic");
+            VA_MARK(c.dtype == VA_U8 && p->planes_wp ? "gauss_planes" : "gauss_generic");
         }
     } else if (filtered_out) {
         VA_HIP(hipMemcpyAsync(filtered_out, cur, (size_t)n * p->px * esz, hipMemcpyDeviceToDevice,
