@@ -864,7 +864,9 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
             if (rc)
                 return rc;
             cur = dst;
-            VA_MARK(c.dtype == VA_U8 && p->planes_wp ? "gauss_planes" : "gauss_generic");
+            VA_MARK(c.dtype == VA_U8 ? (p->planes_wp ? "gauss_planes" : "gauss_generic")
+                                     : (gauss_f32_fast_supported(c.width, c.channels, p->tf) ? "gauss_f32"
+                                                                                             : "gauss_generic"));
         }
     } else if (filtered_out) {
         VA_HIP(hipMemcpyAsync(filtered_out, cur, (size_t)n * p->px * esz, hipMemcpyDeviceToDevice,
