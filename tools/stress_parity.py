@@ -51,9 +51,12 @@ def main():
                 f[(xx - cx[k] - vx[k] * t) ** 2 + (yy - cy[k] - vy[k] * t) ** 2 <= rad[k] ** 2] += 60
             f[rng.random((h, w)) < 0.003] = 255
             clip[t] = np.clip(f, 0, 255).astype(np.uint8)
+        with_stats = rng.random() < 0.3              # per-label statistics come from the paint pass
         eng = FrameEngine(size=(w, h), max_batch=n, background=None if bg == "none" else bg, sigma=sigma,
-                          thresh=thresh, morphology=morph, connectivity=conn)
-        out = eng.run(clip, want=("filtered", "mask", "labels", "counts"))
+                          thresh=thresh, morphology=morph, connectivity=conn,
+                          max_labels=48 if with_stats else 0)
+        want = ("filtered", "mask", "labels", "counts") + (("stats",) if with_stats else ())
+        out = eng.run(clip, want=want)
         eng.close()
         cur = clip
         if bg == "mean":
@@ -65,6 +68,15 @@ def main():
         rl, rc = O.label_batch(m, conn)
         ok = (np.array_equal(out["filtered"], blur) and np.array_equal(out["mask"], m)
               and np.array_equal(out["labels"], rl) and np.array_equal(out["counts"], rc))
+        if ok and with_stats:
+            for f in range(0, n, max(1, n // 5)):
+                c = min(int(rc[f]), 48)
+                ok = ok and np.array_equal(out["stats"][f, :c, :14], O.region_stats(rl[f], int(rc[f]))[:c, :14])
+        if ok and case % 7 == 0 and m[0].any():       # contour of the largest region (8-conn roots + tracing)
+            from video.analysis import regions
+            ref, ref_area = O.get_contour_from_largest_region(m[0], ret_area=True)
+            got, area = regions.get_contour_from_largest_region(m[0], ret_area=True)
+            ok = np.array_equal(got, ref) and area == ref_area
         print("case %d: n=%d %dx%d sigma=%.1f t=%d conn=%d bg=%s morph=%s -> %s"
               % (case, n, w, h, sigma, thresh, conn, bg, morph, "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
