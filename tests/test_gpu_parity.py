@@ -321,7 +321,8 @@ def test_label_golden_scipy_vectors(ops, golden, ccl_mode):
                                                (257, 129, 0.55, 3), (480, 640, 0.45, 4),
                                                (31, 2100, 0.5, 5), (300, 65, 0.7, 6),
                                                (128, 4160, 0.59, 7), (1, 500, 0.5, 8),
-                                               (500, 1, 0.5, 9)])
+                                               (500, 1, 0.5, 9), (70, 3840, 0.5, 10),
+                                               (45, 2500, 0.62, 11)])
 def test_label_random_vs_oracle(ops, oracle, h, w, density, seed, ccl_mode):
     rng = np.random.default_rng(seed)
     m = (rng.random((3, h, w)) < density).astype(np.uint8)
@@ -388,6 +389,21 @@ def test_label_4k_frame(ops, oracle):
     m[0, 500:900, 1000:3000] = 1
     lab, cnt = ops.label(m, 4)
     rl, rc = oracle.label_batch(m, 4)
+    assert np.array_equal(cnt, rc) and np.array_equal(lab, rl)
+    # blobs instead of noise: few enough runs for the per-frame kernel (4 rows per wave at 4K)
+    from video import _hip
+    b = np.zeros((1, 2160, 3840), np.uint8)
+    yy, xx = np.mgrid[:2160, :3840]
+    for k in range(60):
+        cx, cy, r = rng.uniform(0, 3840), rng.uniform(0, 2160), rng.uniform(10, 120)
+        b[0][(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = 1
+    b[0][rng.random((2160, 3840)) < 0.0005] = 1
+    rl, rc = oracle.label_batch(b, 8)
+    _hip.check(_hip.lib().va_test_hook_labelling(2, 0))
+    try:
+        lab, cnt = ops.label(b, 8)
+    finally:
+        _hip.check(_hip.lib().va_test_hook_labelling(0, 0))
     assert np.array_equal(cnt, rc) and np.array_equal(lab, rl)
 
 

@@ -328,21 +328,23 @@ __device__ __forceinline__ int flatten_span(const uint32_t *row, int32_t *L, int
     return cnt;
 }
 
-// sum over the 8 word groups of each row (lanes with equal lane & 7)
+// sum over the word groups of each row (lanes with equal lane & (RPW - 1)); RPW rows per wave
+template <int RPW = 8>
 __device__ __forceinline__ int row_sum(int v)
 {
-    v += __shfl_xor(v, 8, kWave);
-    v += __shfl_xor(v, 16, kWave);
-    v += __shfl_xor(v, 32, kWave);
+#pragma unroll
+    for (int o = RPW; o < kWave; o <<= 1)
+        v += __shfl_xor(v, o, kWave);
     return v;
 }
 
-// exclusive prefix over the word groups of each row (lanes lane & 7, lane & 7 + 8, ...)
+// exclusive prefix over the word groups of each row (lanes r, r + RPW, r + 2 RPW, ...)
+template <int RPW = 8>
 __device__ __forceinline__ int row_prefix(int v, int lane)
 {
     int incl = v;
 #pragma unroll
-    for (int o = 8; o < kWave; o <<= 1) {
+    for (int o = RPW; o < kWave; o <<= 1) {
         int t = __shfl_up(incl, o, kWave);
         if (lane >= o)
             incl += t;
@@ -418,6 +420,7 @@ ccl_rowscan_kernel(const int32_t *__restrict__ row_cnt, int32_t *__restrict__ ro
 
 // ---- K5: roots get their final label, stored negated ----------------------------------------
 // all lanes of the wave must call (shuffles); `valid` lanes own a row and a non-empty span
+template <int RPW = 8>
 __device__ __forceinline__ void rank_span(const uint32_t *row, int32_t *L, int y, int w, int w32,
                                           int w0, int w1, int lane, bool valid, int row_offset)
 {
@@ -441,7 +444,7 @@ __device__ __forceinline__ void rank_span(const uint32_t *row, int32_t *L, int y
             }
         }
     }
-    const int before = row_prefix(nroots, lane);
+    const int before = row_prefix<RPW>(nroots, lane);
     if (!valid)
         return;
     int k = row_offset + before;
@@ -501,11 +504,11 @@ ccl_rank_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
 // the chip-wide passes was measured: five near-empty launches cost every batch 4 %).
 constexpr int kFrameThreads = 1024;
 constexpr int kFrameWaves = kFrameThreads / kWave;                // 16
-constexpr int kFrameRowsPerIter = kFrameWaves * kRowsPerWave;     // 128 rows per sweep step
 constexpr int kFrameLdsWords = 37 * 1024;                         // 148 KB, partitioned per launch
 constexpr int kQueue = 128;                                       // queued pairs per wave
 constexpr int kMinLdsRuns = 4096;                                 // else: chip-wide path
-constexpr int kMaxFrameWords = 80 * 1024;                         // mask words per frame (1080p: 64.8 k)
+constexpr int kMaxFrameWords = 320 * 1024;                        // mask words per frame (1080p: 64.8 k, 4K: 259 k)
+constexpr int kWantLdsRuns = 16384;                               // below: try 4 rows per wave (smaller stages)
 constexpr int kNonRootBit = 1 << 30;
 
 constexpr int kChunk = 8;                                         // words per lane and chunk
@@ -516,12 +519,17 @@ struct FrameLayout {   // word offsets into the kernel's LDS array
     int stage_words;   // per wave: 9 staged rows of the mask
     int queue_off, rowbase_off, parent_off, lds_runs;
 };
-inline int span_chunks(int w32) { return (((w32 + 7) >> 3) + kChunk - 1) / kChunk; }
-inline FrameLayout frame_layout(int h, int w32)
+// rpw rows per wave (8 or 4) <-> 64 / rpw lanes per row, each with span_chunks() chunks of 8 words
+inline int span_chunks(int w32, int rpw)
+{
+    const int groups = kWave / rpw;
+    return ((w32 + groups - 1) / groups + kChunk - 1) / kChunk;
+}
+inline FrameLayout frame_layout(int h, int w32, int rpw)
 {
     FrameLayout l;
-    l.row_stride = kStagePad + 8 * span_chunks(w32) * kChunk + 4;
-    l.stage_words = (kRowsPerWave + 1) * l.row_stride;
+    l.row_stride = kStagePad + (kWave / rpw) * span_chunks(w32, rpw) * kChunk + 4;
+    l.stage_words = (rpw + 1) * l.row_stride;
     l.queue_off = kFrameWaves * l.stage_words;
     l.rowbase_off = l.queue_off + kFrameWaves * 2 * kQueue;
     l.parent_off = l.rowbase_off + ((h + 1 + 3) & ~3);
@@ -590,14 +598,14 @@ struct FrameSpan {
     bool valid;   // this lane has a row of the frame
     int lane, r, y, w0, w1;   // word span [w0, w1): NCH whole chunks (zero-padded in the stage)
 };
-template <int NCH>
+template <int NCH, int RPW>
 __device__ __forceinline__ FrameSpan frame_span(int y0, int h, int w32)
 {
     FrameSpan c;
     c.lane = threadIdx.x & (kWave - 1);
-    c.r = c.lane & (kRowsPerWave - 1);
+    c.r = c.lane & (RPW - 1);
     c.y = y0 + c.r;
-    c.w0 = (c.lane >> 3) * NCH * kChunk;
+    c.w0 = (c.lane / RPW) * NCH * kChunk;
     c.w1 = min(w32, c.w0 + NCH * kChunk);    // large-frame mode reads global memory: real bounds
     c.valid = c.y < h;
     return c;
@@ -675,7 +683,7 @@ __device__ __forceinline__ void scan_rows(int *rowbase, int h, int *s_part, int 
     __syncthreads();
 }
 
-template <bool CONN8, int NCH>
+template <bool CONN8, int NCH, int RPW>
 __global__ void __launch_bounds__(kFrameThreads)
 ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
                  int32_t *__restrict__ counts, int h, int w, int w32, FrameLayout lay, int vec)
@@ -694,7 +702,8 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     int *queue = s_mem + lay.queue_off + wv * 2 * kQueue;
     int *rowbase = s_mem + lay.rowbase_off;
     int *parent = s_mem + lay.parent_off;
-    const int sweeps = (h + kFrameRowsPerIter - 1) / kFrameRowsPerIter;
+    constexpr int kRowsPerIter = kFrameWaves * RPW;         // rows per sweep step of the workgroup
+    const int sweeps = (h + kRowsPerIter - 1) / kRowsPerIter;
 
     // stage image rows y0 - 1 ... y0 + 7 of this wave's sweep step (slot 0 is the row above y0).
     // All nine loads are issued before any is used -- one memory round trip per sweep step --
@@ -702,20 +711,20 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     // edge row, and no lane that reads them is `valid`.
     typedef int v4i __attribute__((ext_vector_type(4)));
     struct RowRegs {
-        v4i v[kRowsPerWave + 1];   // 16 bytes of each row (vec) or words lane, lane + 64 in .x, .y
+        v4i v[RPW + 1];   // 16 bytes of each row (vec) or words lane, lane + 64 in .x, .y
     };
     auto issue_rows = [&](int y0, RowRegs &rr) {
         if (vec) {
             const int col = min(lane * 4, w32 - 4);
 #pragma unroll
-            for (int j = 0; j <= kRowsPerWave; j++) {
+            for (int j = 0; j <= RPW; j++) {
                 const int y = min(max(y0 - 1 + j, 0), h - 1);
                 rr.v[j] = *reinterpret_cast<const v4i *>(fbits + (size_t)y * w32 + col);
             }
         } else {
             const int c0 = min(lane, w32 - 1), c1 = min(lane + kWave, w32 - 1);   // w32 <= 128
 #pragma unroll
-            for (int j = 0; j <= kRowsPerWave; j++) {
+            for (int j = 0; j <= RPW; j++) {
                 const uint32_t *src = fbits + (size_t)min(max(y0 - 1 + j, 0), h - 1) * w32;
                 rr.v[j].x = (int)src[c0];
                 rr.v[j].y = (int)src[c1];
@@ -727,12 +736,12 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         if (vec) {
             if (lane * 4 < w32) {
 #pragma unroll
-                for (int j = 0; j <= kRowsPerWave; j++)
+                for (int j = 0; j <= RPW; j++)
                     *reinterpret_cast<v4i *>(stage + j * rs + lane * 4) = rr.v[j];
             }
         } else {
 #pragma unroll
-            for (int j = 0; j <= kRowsPerWave; j++) {
+            for (int j = 0; j <= RPW; j++) {
                 if (lane < w32)
                     stage[j * rs + lane] = rr.v[j].x;
                 if (lane + kWave < w32)
@@ -749,14 +758,14 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
 
     // ---- 1. runs per row, exclusive scan -> first run id of every row -----------------------
     for (int it = 0; it < sweeps; it++) {
-        const int y0 = it * kFrameRowsPerIter + wv * kRowsPerWave;
+        const int y0 = it * kRowsPerIter + wv * RPW;
         stage_rows(y0);
-        const FrameSpan c = frame_span<NCH>(y0, h, w32);
+        const FrameSpan c = frame_span<NCH, RPW>(y0, h, w32);
         uint32_t mw[NCH][kChunk + 2];
         load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
         int n = c.valid ? count_starts<NCH>(mw) : 0;
-        n = row_sum(n);
-        if (lane < kRowsPerWave && c.y < h)
+        n = row_sum<RPW>(n);
+        if (lane < RPW && c.y < h)
             rowbase[c.y] = n;
     }
     __syncthreads();
@@ -766,22 +775,22 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     if (nruns > lay.lds_runs) {
         // ---- large-frame mode: forest in the label image, same passes as the chip-wide path ---
         for (int it = 0; it < sweeps; it++) {
-            const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
+            const FrameSpan c = frame_span<NCH, RPW>(it * kRowsPerIter + wv * RPW, h, w32);
             if (c.valid && c.w0 < c.w1)
                 init_span(fbits + (size_t)c.y * w32, L, c.y, w, w32, c.w0, c.w1);
         }
         __syncthreads();
         for (int it = 0; it < sweeps; it++) {
-            const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
+            const FrameSpan c = frame_span<NCH, RPW>(it * kRowsPerIter + wv * RPW, h, w32);
             if (c.valid && c.w0 < c.w1 && c.y > 0)
                 link_span<CONN8>(fbits + (size_t)c.y * w32, L, c.y, w, w32, c.w0, c.w1);
         }
         __syncthreads();
         for (int it = 0; it < sweeps; it++) {
-            const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
+            const FrameSpan c = frame_span<NCH, RPW>(it * kRowsPerIter + wv * RPW, h, w32);
             int n = c.valid && c.w0 < c.w1 ? flatten_span(fbits + (size_t)c.y * w32, L, c.y, w, w32, c.w0, c.w1) : 0;
-            n = row_sum(n);
-            if (lane < kRowsPerWave && c.y < h)
+            n = row_sum<RPW>(n);
+            if (lane < RPW && c.y < h)
                 rowbase[c.y] = n;
         }
         __syncthreads();
@@ -789,10 +798,10 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         if (tid == 0 && counts)
             counts[f] = s_total;
         for (int it = 0; it < sweeps; it++) {
-            const FrameSpan c = frame_span<NCH>(it * kFrameRowsPerIter + wv * kRowsPerWave, h, w32);
+            const FrameSpan c = frame_span<NCH, RPW>(it * kRowsPerIter + wv * RPW, h, w32);
             const int yy = c.y < h ? c.y : 0;
             const bool ok = c.valid && c.w0 < c.w1;
-            rank_span(fbits + (size_t)yy * w32, L, c.y, w, w32, c.w0, c.w1, lane, ok,
+            rank_span<RPW>(fbits + (size_t)yy * w32, L, c.y, w, w32, c.w0, c.w1, lane, ok,
                       ok ? rowbase[c.y] : 0);
         }
         return;
@@ -817,9 +826,9 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
 
     // ---- 3. link runs of row y with runs of row y-1 -----------------------------------------------
     for (int it = 0; it < sweeps; it++) {
-        const int y0 = it * kFrameRowsPerIter + wv * kRowsPerWave;
+        const int y0 = it * kRowsPerIter + wv * RPW;
         stage_rows(y0);
-        const FrameSpan c = frame_span<NCH>(y0, h, w32);
+        const FrameSpan c = frame_span<NCH, RPW>(y0, h, w32);
         const bool act = c.valid && c.y > 0;
         uint32_t mw[NCH][kChunk + 2], uw[NCH][kChunk + 2];
         load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
@@ -827,7 +836,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         const int nc = act ? count_starts<NCH>(mw) : 0;
         const int nu = act ? count_starts<NCH>(uw) : 0;
         // runs of the row that start left of this lane's span
-        int cc = row_prefix(nc, lane), cu = row_prefix(nu, lane);
+        int cc = row_prefix<RPW>(nc, lane), cu = row_prefix<RPW>(nu, lane);
         // contacts of this lane's span (the same bit tricks as below, counted)
         int ncontacts = 0;
         if (act) {
@@ -937,16 +946,16 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         return v;
     };
     RowRegs rr;
-    issue_rows(wv * kRowsPerWave, rr);
+    issue_rows(wv * RPW, rr);
     for (int it = 0; it < sweeps; it++) {
-        const int y0 = it * kFrameRowsPerIter + wv * kRowsPerWave;
+        const int y0 = it * kRowsPerIter + wv * RPW;
         commit_rows(rr);
-        issue_rows(y0 + kFrameRowsPerIter, rr);         // clamped rows past the frame: harmless
-        const FrameSpan c = frame_span<NCH>(y0, h, w32);
+        issue_rows(y0 + kRowsPerIter, rr);         // clamped rows past the frame: harmless
+        const FrameSpan c = frame_span<NCH, RPW>(y0, h, w32);
         uint32_t mw[NCH][kChunk + 2];
         load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
         const int nc = c.valid ? count_starts<NCH>(mw) : 0;
-        int id = row_prefix(nc, lane);
+        int id = row_prefix<RPW>(nc, lane);
         int nq_total;
         int slot = wave_prefix(nc, &nq_total);
         if (c.valid) {
@@ -1385,6 +1394,19 @@ void ccl_test_hook(int path, int lds_runs)
     g_ccl_lds_runs = lds_runs;
 }
 
+// rows per wave the per-frame kernel would use (8; 4 for wide frames, whose nine-row stages
+// would leave too little LDS for the run table), 0 when the frame does not fit at all
+static int frame_rows_per_wave(int h, int w32)
+{
+    if ((long long)h * w32 > kMaxFrameWords || w32 > 128)    // (the row staging covers 128 words)
+        return 0;
+    for (int rpw = 8; rpw >= 4; rpw >>= 1)
+        if (span_chunks(w32, rpw) <= 2 &&
+            frame_layout(h, w32, rpw).lds_runs >= (rpw == 8 ? kWantLdsRuns : kMinLdsRuns))
+            return rpw;
+    return span_chunks(w32, 8) <= 2 && frame_layout(h, w32, 8).lds_runs >= kMinLdsRuns ? 8 : 0;
+}
+
 bool ccl_frame_kernel_used(int n, int h, int w)
 {
     if (g_ccl_path == 1)
@@ -1398,11 +1420,7 @@ bool ccl_frame_kernel_used(int n, int h, int w)
         if (t_frame >= t_chip && g_ccl_path != 2)
             return false;
     }
-    const int w32 = words_per_row(w);
-    // larger frames (4K) overflow the run table too often and leave CUs idle: chip-wide passes
-    if ((long long)h * w32 > kMaxFrameWords)
-        return false;
-    return span_chunks(w32) <= 2 && frame_layout(h, w32).lds_runs >= kMinLdsRuns;
+    return frame_rows_per_wave(h, words_per_row(w)) != 0;
 }
 
 // [row_cnt][row_off]
@@ -1471,23 +1489,23 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     };
     if (ccl_frame_kernel_used(n, h, w)) {
         // one workgroup per frame, forest in LDS
-        FrameLayout lay = frame_layout(h, w32);
+        const int rpw = frame_rows_per_wave(h, w32);
+        FrameLayout lay = frame_layout(h, w32, rpw);
         if (g_ccl_lds_runs > 0)                            // test hook: force the large-frame mode
             lay.lds_runs = min(lay.lds_runs, g_ccl_lds_runs);
         const int vec = (w32 % 4 == 0) && aligned(bits, 16);
-#define VA_FRAME_LAUNCH(C8, NCH) \
-    ccl_frame_kernel<C8, NCH><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, vec)
-        if (span_chunks(w32) == 1) {
-            if (connectivity == 8)
-                VA_FRAME_LAUNCH(true, 1);
-            else
-                VA_FRAME_LAUNCH(false, 1);
-        } else {
-            if (connectivity == 8)
-                VA_FRAME_LAUNCH(true, 2);
-            else
-                VA_FRAME_LAUNCH(false, 2);
-        }
+        const int nch = span_chunks(w32, rpw);
+#define VA_FRAME_LAUNCH(C8, NCH, RPW) \
+    ccl_frame_kernel<C8, NCH, RPW><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, vec)
+#define VA_FRAME_CASE(NCH, RPW)                 \
+    if (nch == NCH && rpw == RPW) {             \
+        if (connectivity == 8)                  \
+            VA_FRAME_LAUNCH(true, NCH, RPW);    \
+        else                                    \
+            VA_FRAME_LAUNCH(false, NCH, RPW);   \
+    }
+        VA_FRAME_CASE(1, 8) VA_FRAME_CASE(2, 8) VA_FRAME_CASE(1, 4) VA_FRAME_CASE(2, 4)
+#undef VA_FRAME_CASE
 #undef VA_FRAME_LAUNCH
         VA_LAUNCH_CHECK("ccl_frame_kernel");
         VA_MARK("ccl_frame");
