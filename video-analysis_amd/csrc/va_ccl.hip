@@ -1411,16 +1411,21 @@ bool ccl_frame_kernel_used(int n, int h, int w)
 {
     if (g_ccl_path == 1)
         return false;
-    // One CU per frame costs the same whatever the batch size (up to one frame per CU), the
-    // chip-wide passes scale with the batch: measured ~0.106 ms per 1080p frame set against
-    // ~0.277 ms per 256 x 1080p frames plus ~0.03 ms of launches (four more kernels).
-    {
-        const double wf = (double)h * words_per_row(w) / 64800.0;     // frame size in 1080p frames
-        const double t_frame = 0.106 * wf + 0.01, t_chip = 0.277 * wf * n / 256.0 + 0.03;
-        if (t_frame >= t_chip && g_ccl_path != 2)
+    const int rpw = frame_rows_per_wave(h, words_per_row(w));
+    if (rpw == 0)
+        return false;
+    // Cost model from measurements of the whole chain (tools/labelling_paths.py; ms, frame size wf
+    // in 1080p frames): the chip-wide passes scale with the batch and pay four more launches; one
+    // workgroup per frame grows only mildly with the batch (contention), and its 4-rows-per-wave
+    // form for wide frames is slower per word.
+    if (g_ccl_path != 2) {
+        const double wf = (double)h * words_per_row(w) / 64800.0, fill = (double)min(n, 256) / 256.0;
+        const double t_frame = wf * (rpw == 8 ? 0.04 + 0.066 * fill : 0.075) + 0.01;
+        const double t_chip = 0.277 * wf * n / 256.0 + 0.03;
+        if (t_frame >= t_chip)
             return false;
     }
-    return frame_rows_per_wave(h, words_per_row(w)) != 0;
+    return true;
 }
 
 // [row_cnt][row_off]
