@@ -30,7 +30,7 @@ def main():
         h = int(rng.integers(32, 200)) if not big else int(rng.integers(100, 420))
         w = int(rng.choice([64, 80, 96, 112, 128, 160, 208, 256, 272, 320, int(rng.integers(33, 300))]))
         if big:
-            w = int(rng.choice([640, 1280, 1920, 1936, 2048, 2064]))
+            w = int(rng.choice([640, 1280, 1920, 1936, 2048, 2064, 2560, 3840, 4000]))
         n = int(rng.choice([1, 3, 7, 96, 100, 130])) if not big else int(rng.choice([2, 97]))
         sigma = float(rng.choice([0.6, 0.8, 1.0, 1.7, 2.0, 3.0, 4.2, 5.0, 5.3, 6.0]))
         thresh = int(rng.integers(5, 60))
