@@ -152,6 +152,21 @@ def test_rect_helpers():
     assert regions.rect_to_corners((2, 3, 4, 5)) == ((2, 3), (5, 7))
     assert regions.rect_to_corners((2, 3, 4, 5), 4) == ((2, 3), (5, 3), (5, 7), (2, 7))
     assert regions.expand_rectangle((2, 3, 4, 5), 2) == (0, 1, 8, 9)
+    # get_overlapping_slices (reference :57-110): template fully inside, cut at a corner, anchors
+    sl = regions.get_overlapping_slices((10, 8), (4, 6), (20, 30))
+    assert sl == ((slice(0, 4), slice(0, 6)), (slice(6, 10), slice(7, 13)))
+    sl, rect = regions.get_overlapping_slices((1, 0), (4, 6), (20, 30), ret_rect=True)
+    assert sl == ((slice(2, 4), slice(2, 6)), (slice(0, 2), slice(0, 4))) and rect == (0, 0, 4, 2)
+    sl = regions.get_overlapping_slices((28, 18), (4, 6), (20, 30), anchor='upper left')
+    assert sl == ((slice(0, 2), slice(0, 2)), (slice(18, 20), slice(28, 30)))
+    for pos in ((-10, 5), (5, -10), (40, 5), (5, 40)):
+        with pytest.raises(RuntimeError):
+            regions.get_overlapping_slices(pos, (4, 6), (20, 30))
+    with pytest.raises(ValueError):
+        regions.get_overlapping_slices((0, 0), (4, 6), (20, 30), anchor='middle')
+    assert regions.triangle_area(3, 4, 5) == 6 and regions.triangle_area(1, 1, 3) == 0
+    assert np.allclose(regions.triangle_area(np.array([3.0, 1.0]), np.array([4.0, 1.0]), np.array([5.0, 3.0])),
+                       [6.0, 0.0])
     with pytest.raises(ValueError):
         regions.rect_to_corners((0, 0, 1, 1), 3)
 

@@ -1,8 +1,8 @@
 """Region helpers: rectangles (host arithmetic) and blob detection (GPU).
 
 Reference: video/analysis/regions.py -- corners_to_rect :23-29, rect_to_corners :33-45,
-rect_to_slices :49-53, find_bounding_box :113-149, expand_rectangle :153-155,
-get_largest_region :159-174.
+rect_to_slices :49-53, get_overlapping_slices :57-110, find_bounding_box :113-149,
+expand_rectangle :153-155, get_largest_region :159-174, triangle_area :430-451.
 """
 import numpy as np
 
@@ -28,6 +28,48 @@ def rect_to_corners(rect, count=2):
 def rect_to_slices(rect):
     """(slice_y, slice_x) selecting the rectangle from an array"""
     return slice(rect[1], rect[1] + rect[3]), slice(rect[0], rect[0] + rect[2])
+
+
+def get_overlapping_slices(t_pos, t_shape, i_shape, anchor='center', ret_rect=False):
+    """slices that cut the common part out of a template placed in a larger image
+    (reference :57-110).  t_pos = (x, y) of the template's anchor in the image, t_shape =
+    (height, width) of the template, i_shape = (height, width) of the image.  Returns
+    ((template_rows, template_cols), (image_rows, image_cols)) and, with ret_rect, the common
+    rectangle (left, top, width, height) in image coordinates; RuntimeError if nothing overlaps."""
+    th, tw = t_shape[0], t_shape[1]
+    if anchor == 'center':
+        left, top = t_pos[0] - tw // 2, t_pos[1] - th // 2
+    elif anchor == 'upper left':
+        left, top = t_pos[0], t_pos[1]
+    else:
+        raise ValueError('Unknown anchor point: %s' % anchor)
+
+    def overlap(start, t_len, i_len):
+        """(image start, template start, length) along one axis"""
+        length = min(t_len, i_len - start)
+        if length <= 0 or start <= -t_len:
+            raise RuntimeError('Template and image do not overlap')
+        if start >= 0:
+            return start, 0, length
+        return 0, -start, length + start
+
+    i_x, t_x, w = overlap(left, tw, i_shape[1])
+    i_y, t_y, h = overlap(top, th, i_shape[0])
+    slices = ((slice(t_y, t_y + h), slice(t_x, t_x + w)),
+              (slice(i_y, i_y + h), slice(i_x, i_x + w)))
+    if ret_rect:
+        return slices, (i_x, i_y, w, h)
+    return slices
+
+
+def triangle_area(a, b, c):
+    """area of a triangle with side lengths a, b, c (numbers or arrays) by Heron's formula;
+    radicands that rounding made negative give 0 (reference :430-451)"""
+    s = (a + b + c) / 2
+    radicand = s * (s - a) * (s - b) * (s - c)
+    if isinstance(radicand, np.ndarray):
+        return np.sqrt(np.where(radicand > 0, radicand, 0))
+    return np.sqrt(radicand) if radicand > 0 else 0
 
 
 def expand_rectangle(rect, amount=1):
