@@ -94,6 +94,34 @@ template <int PIECES, int OFF> void run4(const char *name, v4i *d, size_t bytes)
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     printf("%-40s: %.3f ms per pass -> %.2f TB/s\n", name, ms / 5, bytes / (ms / 5 * 1e-3) / 1e12);
 }
+// eight waves share eight 7680-byte rows: wave i writes piece i of every row (its consecutive
+// stores are a row apart instead of adjacent)
+__global__ void fill_rows_transposed(v4i *p, size_t rows, int v)
+{
+    const v4i val = {v, v, v, v};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t row0 = (size_t)blockIdx.x * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const size_t row = row0 + j;
+        const int e = wave * 64 + lane;
+        if (row < rows && e < 480)
+            p[row * 480 + e] = val;
+    }
+}
+void run5(const char *name, v4i *d, size_t bytes)
+{
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const size_t rows = bytes / 7680;
+    fill_rows_transposed<<<(unsigned)((rows + 7) / 8), 512>>>(d, rows, 1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 5; r++)
+        fill_rows_transposed<<<(unsigned)((rows + 7) / 8), 512>>>(d, rows, r);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-40s: %.3f ms per pass -> %.2f TB/s\n", name, ms / 5, bytes / (ms / 5 * 1e-3) / 1e12);
+}
 template <int WPR> void run3(const char *name, v4i *d, size_t bytes)
 {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -154,6 +182,7 @@ int main()
     run4<8, 512>("wave = 8 KB at a 512-B offset", d, bytes);
     run4<1, 512>("wave = 1 KB at a 512-B offset", d, bytes);
     run4<2, 0>("wave = 2 aligned KB", d, bytes);
+    run5("8 rows x 8 waves, wave = piece column", d, bytes);
     run3<2>("row over 2 waves (4 x 1 KB each), plain", d, bytes);
     run3<4>("row over 4 waves (2 x 1 KB each), plain", d, bytes);
     run3<8>("row over 8 waves (1 x 1 KB each), plain", d, bytes);
