@@ -122,6 +122,37 @@ void run5(const char *name, v4i *d, size_t bytes)
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     printf("%-40s: %.3f ms per pass -> %.2f TB/s\n", name, ms / 5, bytes / (ms / 5 * 1e-3) / 1e12);
 }
+// a wave writes its row's 8 pieces with a pause between the stores
+template <int SLEEP>
+__global__ void fill_rows_paced(v4i *p, size_t rows, int v)
+{
+    const v4i val = {v, v, v, v};
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows)
+        return;
+    v4i *q = p + row * 480;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int e = i * 64 + lane;
+        if (e < 480)
+            q[e] = val;
+        __builtin_amdgcn_s_sleep(SLEEP);
+    }
+}
+template <int SLEEP> void run6(const char *name, v4i *d, size_t bytes)
+{
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const size_t rows = bytes / 7680;
+    fill_rows_paced<SLEEP><<<(unsigned)((rows + 3) / 4), 256>>>(d, rows, 1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 5; r++)
+        fill_rows_paced<SLEEP><<<(unsigned)((rows + 3) / 4), 256>>>(d, rows, r);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-40s: %.3f ms per pass -> %.2f TB/s\n", name, ms / 5, bytes / (ms / 5 * 1e-3) / 1e12);
+}
 template <int WPR> void run3(const char *name, v4i *d, size_t bytes)
 {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -183,6 +214,9 @@ int main()
     run4<1, 512>("wave = 1 KB at a 512-B offset", d, bytes);
     run4<2, 0>("wave = 2 aligned KB", d, bytes);
     run5("8 rows x 8 waves, wave = piece column", d, bytes);
+    run6<2>("row per wave, s_sleep 2 between stores", d, bytes);
+    run6<8>("row per wave, s_sleep 8 between stores", d, bytes);
+    run6<32>("row per wave, s_sleep 32 between stores", d, bytes);
     run3<2>("row over 2 waves (4 x 1 KB each), plain", d, bytes);
     run3<4>("row over 4 waves (2 x 1 KB each), plain", d, bytes);
     run3<8>("row over 8 waves (1 x 1 KB each), plain", d, bytes);
