@@ -65,6 +65,16 @@ STAGE_BYTES_PER_PX = {
 }
 
 
+# float32 side workload: bytes per float element of each stage
+F32_STAGE_BYTES_PER_ELEM = {
+    "bg": 4 + 4,                 # frame in, |frame - bg| out (state amortised over the batch)
+    "gauss_f32": 4 + 4,          # difference in, blurred out (the row-pass intermediate is NOT compulsory)
+    "gauss_generic": 4 + 4,
+    "ema_row_f32": 4 + 4,        # fused EMA + row pass: frame in, row-filtered difference out
+    "col_f32": 4 + 4,            # column pass: row-filtered in, blurred out
+}
+
+
 def synth_batch(torch, device, w, h, n, blobs, salt, seed):
     """static Gaussian background + per-frame noise + moving discs (+ salt)"""
     g = torch.Generator(device=device)
@@ -93,24 +103,189 @@ def synth_batch(torch, device, w, h, n, blobs, salt, seed):
     return frames
 
 
-def cpu_baseline(frames_host, sigma, thresh, morph, sample_frames):
-    """the oracle's C restatement of the same chain, single thread, bounded sample"""
+def _cpu_count():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def _cpu_chain_frames(args):
+    """worker of the all-core leg: blur -> threshold -> close -> label for frames [a, b) of the
+    background-subtracted sample (memory-mapped), returns the object counts"""
+    path, shape, a, b, sigma, thresh, morph = args
+    import numpy as np
     from oracle import oracle as O
+    diff = np.load(path, mmap_mode="r")
+    counts = []
+    for f in range(a, b):
+        m = O.threshold_u8(O.gaussian_u8(np.ascontiguousarray(diff[f]), sigma), thresh)
+        if morph:
+            m = O.morph_u8(O.morph_u8(m, O.DILATE, O.RECT, morph), O.ERODE, O.RECT, morph)
+        counts.append(O.label(m, 4)[1])
+    return counts
+
+
+def _cpu_bg_strip(args):
+    """worker of the all-core leg: the running mean is sequential in time but pixel-local, so
+    the background pass shards over image rows"""
+    src, dst, shape, ya, yb = args
+    import numpy as np
+    from oracle import oracle as O
+    frames = np.load(src, mmap_mode="r")
+    out = np.lib.format.open_memmap(dst, mode="r+")
+    d, _ = O.bg_mean_u8(np.ascontiguousarray(frames[:, ya:yb]))
+    out[:, ya:yb] = d
+    out.flush()
+    return yb - ya
+
+
+def cpu_baseline_main(argv):
+    """`bench.py --cpu-baseline-child sample.npy sigma thresh morph`: runs in a FRESH process that
+    never touches the GPU (so forking worker processes is safe) and prints one JSON object:
+      value/cores=1 : the oracle's C chain (oracle/va_oracle.c), one thread -- kind "port"
+      all_cores     : the same chain on every host core this process may use: background pass
+                      sharded over image rows (temporal recurrence, pixel-local), then frames
+                      sharded over processes
+      literal_recipe: the reference's own NumPy/SciPy lines where they exist without cv2:
+                      running mean (video/analysis/video.py:33) + ndimage.label + the per-label
+                      np.sum loop (video/analysis/regions.py:162-169), a few frames
+    """
+    import multiprocessing as mp
+    import numpy as np
+    from oracle import oracle as O
+    path, sigma, thresh, morph = argv[0], float(argv[1]), int(argv[2]), int(argv[3])
     O.build()
-    sample = frames_host[:sample_frames]
+    frames = np.load(path)
+    n, h, w = frames.shape
+    cores = _cpu_count()
+    # -- 1 thread
     t0 = time.perf_counter()
-    O.chain_u8(sample, sigma, thresh, morph_ksize=morph, connectivity=4, want_mask=False,
-               want_labels=True)
+    mask, labels, counts, _ = O.chain_u8(frames, sigma, thresh, morph_ksize=morph, connectivity=4,
+                                         want_mask=True, want_labels=True)
+    dt1 = time.perf_counter() - t0
+    res = {"value": round(n / dt1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d of the batch's %dx%d frames, full chain incl. labelling, oracle/va_oracle.c "
+                     "gcc -O3 -march=native, 1 thread of %d usable host cores (os.cpu_count()=%d), %.1f s"
+                     % (n, w, h, cores, os.cpu_count() or 0, dt1)}
+    # -- all cores
+    workers = max(1, min(cores, 64))
+    diff_path = path + ".diff.npy"
+    np.lib.format.open_memmap(diff_path, mode="w+", dtype=np.uint8, shape=frames.shape).flush()
+    ctx = mp.get_context("fork")
+    with ctx.Pool(workers) as pool:
+        pool.map(abs, range(workers))                 # workers up before the clock starts
+        t0 = time.perf_counter()
+        rows = [(path, diff_path, frames.shape, h * k // workers, h * (k + 1) // workers)
+                for k in range(workers) if h * k // workers < h * (k + 1) // workers]
+        pool.map(_cpu_bg_strip, rows)
+        shards = [(diff_path, frames.shape, n * k // workers, n * (k + 1) // workers, sigma, thresh, morph)
+                  for k in range(workers) if n * k // workers < n * (k + 1) // workers]
+        par_counts = [c for part in pool.map(_cpu_chain_frames, shards) for c in part]
+        dtp = time.perf_counter() - t0
+    if list(par_counts) != [int(c) for c in counts]:
+        raise SystemExit("cpu baseline: sharded chain disagrees with the sequential one")
+    res["all_cores"] = {"value": round(n / dtp, 3), "unit": "frames/s", "cores": workers,
+                        "sample": "same %d frames: background pass sharded over image rows, then frames "
+                                  "sharded over %d forked processes, %.1f s" % (n, workers, dtp)}
+    os.unlink(diff_path)
+    # -- the literal reference recipe, where it exists without cv2
+    try:
+        from scipy import ndimage
+        k = min(4, n)
+        t0 = time.perf_counter()
+        mean = np.zeros((h, w), np.double)
+        for i in range(k):                                      # video/analysis/video.py:30-33
+            mean = mean * i / (i + 1) + frames[i] / (i + 1)
+        t_mean = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        nlab = 0
+        for i in range(k):                                      # video/analysis/regions.py:162-169
+            lab, num = ndimage.label(mask[n - 1 - i])
+            areas = [np.sum(lab == l) for l in range(1, num + 1)]
+            nlab += num
+            if areas:
+                int(np.argmax(areas))
+        t_lab = time.perf_counter() - t0
+        res["literal_recipe"] = {
+            "value": round(k / (t_mean + t_lab), 3), "unit": "frames/s", "cores": 1,
+            "stages": "NumPy running mean (video/analysis/video.py:33) + scipy.ndimage.label + per-label "
+                      "np.sum loop + argmax (video/analysis/regions.py:162-169); blur/threshold/morphology "
+                      "are cv2 calls in the reference and cv2 is not installed, so they are NOT in this figure",
+            "sample": "%d frames (%d labels): running mean %.3f s/frame, label + area loop %.3f s/frame"
+                      % (k, nlab, t_mean / k, t_lab / k)}
+    except ImportError:
+        res["literal_recipe"] = None
+    print("CPU_BASELINE_JSON " + json.dumps(res), flush=True)
+
+
+def cpu_baseline_f32_main(argv):
+    """f32 side workload: oracle EMA + sigma-tap float Gaussian on a few frames, 1 thread"""
+    import numpy as np
+    from oracle import oracle as O
+    path, sigma, rate = argv[0], float(argv[1]), float(argv[2])
+    O.build()
+    frames = np.load(path)
+    n = frames.shape[0]
+    t0 = time.perf_counter()
+    diff, _ = O.bg_ema_f32(frames, rate=rate)
+    O.gaussian_f32(diff, sigma)
     dt = time.perf_counter() - t0
-    return {"value": round(len(sample) / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the batch's %dx%d frames, full chain incl. labelling, oracle/va_oracle.c "
-                      "gcc -O3 -march=native, 1 thread of %d host cores, %.1f s"
-                      % (len(sample), frames_host.shape[2], frames_host.shape[1],
-                         os.cpu_count() or 0, dt)}
+    res = {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames %r float32, EMA + sigma=%g Gaussian, oracle/va_oracle.c, 1 thread of %d "
+                     "usable host cores, %.1f s" % (n, frames.shape[1:], sigma, _cpu_count(), dt)}
+    print("CPU_BASELINE_JSON " + json.dumps(res), flush=True)
+
+
+def cpu_baseline(sample, child_args, mode="--cpu-baseline-child"):
+    """times the CPU legs in a fresh child process (this one has initialised the GPU: no fork, no
+    exec here -- a plain subprocess), on a bounded sample saved to /dev/shm"""
+    import subprocess
+    import tempfile
+    import numpy as np
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    fd, path = tempfile.mkstemp(suffix=".npy", prefix="va_bench_sample_", dir=shm)
+    os.close(fd)
+    try:
+        np.save(path, sample)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), mode, path] +
+                             [str(a) for a in child_args], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             universal_newlines=True, timeout=900)
+        for line in out.stdout.splitlines():
+            if line.startswith("CPU_BASELINE_JSON "):
+                return json.loads(line[len("CPU_BASELINE_JSON "):])
+        return {"value": None, "error": (out.stderr or out.stdout)[-400:]}
+    finally:
+        for q in (path, path + ".diff.npy"):
+            if os.path.exists(q):
+                os.unlink(q)
+
+
+def roofline_of(stage, px_bytes_table, units, workload, peak=HBM_PEAK_GBS):
+    """`roofline` object for the dominant stage by device time (HIP events on the launch stream
+    inside the timed region).  `units` = pixels (or float elements) one launch processes."""
+    name, (ms_total, launches) = max(stage.items(), key=lambda kv: kv[1][0])
+    avg_ms = ms_total / max(launches, 1)
+    alg_bytes = px_bytes_table.get(name, 0) * units
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, source = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            table = json.load(open(tpath))
+            traffic = table.get(workload, {}).get(name)
+            if traffic is not None:
+                source = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                          "command (%s), not measured in this run" % table.get("_source", {}).get(workload, "r01_j"))
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+            "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_source": source,
+            "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
 
 
 def bench_f32(args, torch, device, dev_index, rank, world):
-    """side workload (not the headline metric): cfg#5 float32 x 3 channels"""
+    """side workload (not the headline metric): BASELINE.json configs[4], float32 x 3 channels"""
     import numpy as np
     from video.engine import FrameEngine
     w, h, c, batch, sigma, rate = F32_WORKLOADS[args.workload]
@@ -135,17 +310,61 @@ def bench_f32(args, torch, device, dev_index, rank, world):
     stage = eng.stage_times()
     fps = batch * args.steps / dt
     alg = w * h * c * 4 * 2
-    print(json.dumps({"metric": "frames/sec (EMA bg + sigma=9 blur) 1080p float32x3", "value": round(fps, 2),
-                      "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                      "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": args.workload, "engine": eng.description, "batch": batch},
-                      "chain": {"alg_bytes_per_frame": alg, "achieved_GBs": round(alg * fps / 1e9, 1),
-                                "stage_avg_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in stage.items()}}}),
-          flush=True)
+    res = {"metric": "frames/sec (EMA bg + sigma=9 blur) 1080p float32x3", "value": round(fps, 2),
+           "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s: %dx%dx%d float32, batch %d, EMA background (rate %g) + sigma=%g "
+                                  "Gaussian; inputs resident in HBM" % (args.workload, w, h, c, batch, rate, sigma),
+                      "engine": eng.description, "batch": batch},
+           "roofline": roofline_of(stage, F32_STAGE_BYTES_PER_ELEM, w * h * c * batch, args.workload),
+           "chain": {"alg_bytes_per_frame": alg, "achieved_GBs": round(alg * fps / 1e9, 1),
+                     "frac_of_hbm_peak": round(alg * fps / 1e9 / HBM_PEAK_GBS, 5),
+                     "stage_avg_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in stage.items()}}}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames_f32].cpu().numpy(), (sigma, rate),
+                                           "--cpu-baseline-f32-child")
+    print(json.dumps(res), flush=True)
     eng.close()
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1, not yet under torchrun): start the N ranks as fresh child
+    processes through torch.distributed.run BEFORE this process makes any GPU call, relay rank 0's
+    JSON line, and exit with the launcher's code.  (Never re-exec a process that touched the GPU.)"""
+    import socket
+    import subprocess
+    port = args.master_port
+    if port <= 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True)
+    line_out = None
+    for line in proc.stdout:
+        line = line.rstrip("\n")
+        if line.startswith("{") and '"metric"' in line:
+            line_out = line
+        else:
+            print(line, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line_out is not None:
+        print(line_out, flush=True)
+    if rc != 0 or line_out is None:
+        raise SystemExit(rc if rc != 0 else 1)
+    raise SystemExit(0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
+        return cpu_baseline_main(sys.argv[2:])
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-f32-child":
+        return cpu_baseline_f32_main(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -154,11 +373,19 @@ def main():
                     choices=sorted(WORKLOADS) + sorted(F32_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override frames per step per GPU")
     ap.add_argument("--cpu-frames", type=int, default=160, help="frames in the CPU baseline sample")
+    ap.add_argument("--cpu-frames-f32", type=int, default=6, help="frames in the f32 CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port for the self-launched ranks")
+    ap.add_argument("--launcher", action="store_true",
+                    help="go through the torch.distributed.run child launch even for --gpus 1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (CPU tensors) only to rehearse the multi-rank "
                          "control flow on a box with fewer GPUs than ranks")
     args = ap.parse_args()
+
+    under_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_torchrun and (args.gpus > 1 or args.launcher):
+        return launch_ranks(args, [a for a in sys.argv[1:] if a != "--launcher"])
 
     import numpy as np
     import torch
@@ -167,27 +394,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPUs visible"
+                         % (rank, local_rank, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or under_torchrun:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    distributed = dist.is_initialized()
 
     from video.engine import FrameEngine
     from video.sharding import gather_counts
 
     if args.workload in F32_WORKLOADS:
-        return bench_f32(args, torch, device, dev_index, rank, world)
+        if world > 1:
+            raise SystemExit("the float32 side workload is a single-GPU bench")
+        rc = bench_f32(args, torch, device, dev_index, rank, world)
+        if distributed:
+            dist.destroy_process_group()
+        return rc
     w, h, batch, sigma, thresh, morph, blobs, salt = WORKLOADS[args.workload]
     if args.batch > 0:
         batch = args.batch
@@ -208,7 +444,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -221,32 +457,22 @@ def main():
     eng.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        all_counts = step()
     fence()
     dt = time.perf_counter() - t0
     stage = eng.stage_times()
     eng.profile(False)
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    if world > 1 and all_counts.numel() != world * batch:
+        raise SystemExit("count gather returned %d entries for %d frames" % (all_counts.numel(), world * batch))
 
     total_frames = world * batch * args.steps
     fps = total_frames / dt
     if rank == 0:
         px = w * h
-        # dominant kernel by device time inside the timed region
-        name, (ms_total, launches) = max(stage.items(), key=lambda kv: kv[1][0])
-        avg_ms = ms_total / max(launches, 1)
-        alg_bytes = STAGE_BYTES_PER_PX.get(name, 0) * px * batch
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
-            except Exception:
-                traffic = None
         chain_bytes_per_frame = px * 1 + px * 4 + 4          # SURVEY.md 8(d) cfg#3: 10 368 004 B @1080p
         stage_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(stage.items())}
         res = {
@@ -267,21 +493,21 @@ def main():
                                    "labelling + object counts; inputs resident in HBM"
                                    % (args.workload, w, h, batch, sigma, thresh,
                                       "%dx%d dilate/erode" % (morph, morph) if morph else "no morphology"),
-                       "frames_per_step_per_gpu": batch, "engine": eng.description},
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes)},
+                       "frames_per_step_per_gpu": batch, "engine": eng.description,
+                       "world_size": dist.get_world_size() if distributed else 1,
+                       "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed
+                                  else "single process"},
+            "roofline": roofline_of(stage, STAGE_BYTES_PER_PX, px * batch, args.workload),
             "chain": {"alg_bytes_per_frame": chain_bytes_per_frame,
                       "achieved_GBs": round(chain_bytes_per_frame * fps / world / 1e9, 2),
                       "frac_of_hbm_peak_per_gpu": round(chain_bytes_per_frame * fps / world / 1e9 / HBM_PEAK_GBS, 5),
                       "stage_avg_ms": stage_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(frames[:max(args.cpu_frames, 1)].cpu().numpy(), sigma,
-                                               thresh, morph, args.cpu_frames)
+            res["cpu_baseline"] = cpu_baseline(frames[:max(args.cpu_frames, 1)].cpu().numpy(),
+                                               (sigma, thresh, morph))
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -21,6 +21,14 @@
  *   - frames are row-major contiguous (N, H, W[, C]); size=(W,H) as in video/io/base.py:119-125.
  *   - bit masks ("bits") are (N, H, ceil(W/32)) uint32, pixel x <-> bit (x & 31) of word x>>5,
  *     padding bits are 0.
+ *   - threads: one device per process (va_init fixes it; every entry point selects it for the
+ *     calling thread).  The stand-alone entry points keep no state between calls: their device
+ *     scratch is a stream-ordered allocation on the call's own `stream`, so different threads may
+ *     call them concurrently on different streams (the reference's VideoPreprocessor workers,
+ *     video/io/parallel.py:398-400).  A va_pipeline_t handle owns its scratch and background
+ *     state and must be used by one thread / one stream at a time.
+ *   - sizes: frames of up to 2^29 - 1 pixels (the kernels address h*w*4 bytes through 32-bit
+ *     buffer descriptors); larger frames are refused with VA_ERR_INVALID.
  */
 #ifndef VIDEOANALYSIS_HIP_H
 #define VIDEOANALYSIS_HIP_H
@@ -57,7 +65,8 @@ extern "C" {
 #define VA_STATS_STRIDE 16 /* int64 per label, see va_moments_i64 */
 
 /* ------------------------------------------------------------------ runtime / errors */
-int va_init(int device);               /* select + warm up the GPU; VA_ERR_NODEV if none     */
+int va_init(int device);               /* select + warm up the GPU; VA_ERR_NODEV if none;
+                                          a second, different device is VA_ERR_INVALID        */
 int va_device_count(void);             /* number of visible GPUs (0 if none / no driver)     */
 const char *va_version(void);
 const char *va_last_error(void);       /* message for the calling thread's last failure      */
@@ -188,6 +197,19 @@ int va_largest_contour(const uint8_t *mask_dev, int n, int h, int w, int32_t *po
                        int32_t *ncomponents_dev, void *workspace_dev, size_t workspace_bytes,
                        void *stream);
 
+/* ------------------------------------------------------------------ A9 contour moments
+ * replaces  cv2.moments(contour), regionprops(contour=...), video/analysis/image.py:355, and
+ *           cv2.moments(np.asarray(self.contour, np.float32)), Polygon.moments,
+ *           video/analysis/shapes.py:527-533
+ * Green's-theorem moments of n closed polygons, accumulated in float64 in OpenCV's point order
+ * (bit-identical to its contourMoments; m00 >= 0 for either orientation; a degenerate contour
+ * gives zeros).  points_dev: (n, max_points, 2) int32 (is_float == 0) or float32 (x, y) -- e.g.
+ * the output of va_largest_contour; npoints_dev[f] = points of contour f (NULL: max_points each).
+ * moments_out_dev: (n, 10) float64 = m00 m10 m01 m20 m11 m02 m30 m21 m12 m03; the central and
+ * normalised moments follow on the host (completeMomentState). */
+int va_contour_moments(const void *points_dev, const int32_t *npoints_dev, int n, int max_points,
+                       int is_float, double *moments_out_dev, void *stream);
+
 /* ------------------------------------------------------------------ N2 small stencils
  * replaces  detect_peaks(img, include_plateaus), video/analysis/image.py:267-306:
  *           ndimage.maximum_filter(img, footprint=8-neighbourhood) == img, minus the
@@ -199,7 +221,8 @@ int va_detect_peaks_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, i
  *           eroded = cv2.erode(img); temp = cv2.dilate(eroded); cv2.subtract(img, temp, temp);
  *           cv2.bitwise_or(skel, temp, skel); img = eroded   ... until img is empty.
  * img_dev is consumed (used as ping-pong scratch with scratch_dev); skel_dev receives the
- * skeleton.  Synchronises the stream once per iteration (the loop's exit test). */
+ * skeleton.  Synchronises the stream once per 16 iterations (the loop's exit test reads one
+ * survivor counter per iteration; steps past the emptying one change nothing). */
 int va_mask_thinning_u8(uint8_t *img_dev, uint8_t *scratch_dev, uint8_t *skel_dev, int h, int w,
                         int *iterations_out, void *stream);
 /* replaces  get_image_statistics, video/analysis/image.py:131-201: local mean and variance in a

@@ -71,6 +71,8 @@ def lib():
                                                            C.c_int64, C.c_void_p, C.c_int]
         _lib.vao_contour_area.argtypes = [C.c_void_p, C.c_int]
         _lib.vao_contour_area.restype = C.c_double
+        _lib.vao_contour_moments.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib.vao_contour_moments.restype = None
         _lib.vao_chain_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
@@ -335,6 +337,23 @@ def contour_area(contour):
     return lib().vao_contour_area(_p(c), len(c))
 
 
+MOMENT_KEYS = ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03",
+               "mu20", "mu11", "mu02", "mu30", "mu21", "mu12", "mu03",
+               "nu20", "nu11", "nu02", "nu30", "nu21", "nu12", "nu03")
+
+
+def contour_moments(contour):
+    """cv2.moments(contour) as a dict of the 24 entries (regionprops(contour=...),
+    video/analysis/image.py:355; Polygon.moments, video/analysis/shapes.py:533).  Integer arrays
+    are taken as int32 points, everything else as float32 points (cv2 accepts only those two)."""
+    c = np.asarray(contour)
+    is_float = 0 if np.issubdtype(c.dtype, np.integer) else 1
+    c = np.ascontiguousarray(c.reshape(-1, 2), np.float32 if is_float else np.int32)
+    sp = np.zeros(10, np.float64)
+    lib().vao_contour_moments(_p(c), len(c), is_float, _p(sp))
+    return dict(zip(MOMENT_KEYS, list(sp) + list(complete_moments(sp))))
+
+
 def get_contour_from_largest_region(mask, ret_area=False):
     """the reference recipe, video/analysis/regions.py:178-197"""
     contours = find_contours_external_simple(mask)
@@ -346,8 +365,36 @@ def get_contour_from_largest_region(mask, ret_area=False):
     return (contour, areas[cid]) if ret_area else contour
 
 
+def _shifted_stack(padded, h, w, offsets):
+    """views of `padded` (padded by 1 on every side) shifted by each (dy, dx) in offsets"""
+    return [padded[1 + dy:1 + dy + h, 1 + dx:1 + dx + w] for dy, dx in offsets]
+
+
+_NBHD8 = [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+
+
 def detect_peaks(img, include_plateaus=True):
-    """LITERAL restatement of detect_peaks (video/analysis/image.py:267-306) with scipy.ndimage"""
+    """detect_peaks (video/analysis/image.py:267-306) in plain NumPy, so that the GPU box needs no
+    SciPy: ndimage.maximum_filter(img, footprint=8-neighbourhood) (default mode 'reflect' repeats
+    the edge pixel, which never changes a 3x3 maximum) and ndimage.binary_erosion(img == 0,
+    8-neighbourhood, border_value=1).  tests/test_oracle_golden.py pins this against the literal
+    scipy.ndimage calls (`detect_peaks_scipy`)."""
+    img = np.asarray(img)
+    h, w = img.shape
+    pad = np.pad(img, 1, mode="edge")
+    if include_plateaus:
+        img_max = np.maximum.reduce(_shifted_stack(pad, h, w, _NBHD8))
+        local_max = (img == img_max)
+        bgp = np.pad(img == 0, 1, mode="constant", constant_values=True)
+        eroded_background = np.logical_and.reduce(_shifted_stack(bgp, h, w, _NBHD8))
+        return local_max ^ eroded_background       # bool `-` of the reference era == XOR
+    img_max = np.maximum.reduce(_shifted_stack(pad, h, w, [o for o in _NBHD8 if o != (0, 0)]))
+    return img > img_max
+
+
+def detect_peaks_scipy(img, include_plateaus=True):
+    """LITERAL restatement of detect_peaks (video/analysis/image.py:267-306) with scipy.ndimage;
+    used by the CPU tests and tests/golden/make_golden.py to pin `detect_peaks`"""
     from scipy import ndimage
     neighborhood = ndimage.generate_binary_structure(2, 2)
     if include_plateaus:
@@ -356,7 +403,7 @@ def detect_peaks(img, include_plateaus=True):
         background = (img == 0)
         eroded_background = ndimage.binary_erosion(background, structure=neighborhood,
                                                    border_value=1)
-        return local_max ^ eroded_background       # bool `-` of the reference era == XOR
+        return local_max ^ eroded_background
     neighborhood[1, 1] = 0
     img_max = ndimage.maximum_filter(img, footprint=neighborhood)
     return img > img_max
@@ -383,27 +430,50 @@ def mask_thinning(img):
     return skel, it
 
 
-def image_statistics(img, kernel="box", ksize=5, prior=None, exclude_center=False):
-    """get_image_statistics (video/analysis/image.py:131-201) with scipy window sums
-    (zero border) in place of cv2.boxFilter / cv2.filter2D; returns (mean, var)"""
-    from scipy import ndimage
+def _window_sums(data, weights):
+    """ndimage.correlate(data, weights, mode='constant', cval=0.0) in plain NumPy: products are
+    accumulated in the footprint's row-major order, like SciPy's loop"""
+    k = weights.shape[0]
+    r = k // 2
+    h, w = data.shape
+    pad = np.pad(np.asarray(data, float), r, mode="constant")
+    out = np.zeros((h, w))
+    for dy in range(k):
+        for dx in range(k):
+            if weights[dy, dx] != 0:
+                out += weights[dy, dx] * pad[dy:dy + h, dx:dx + w]
+    return out
+
+
+def image_statistics(img, kernel="box", ksize=5, prior=None, exclude_center=False, correlate=None):
+    """get_image_statistics (video/analysis/image.py:131-201) with zero-border window sums in
+    place of cv2.boxFilter / cv2.filter2D; returns (mean, var).  Plain NumPy (no SciPy on the GPU
+    box); `correlate` lets the CPU tests substitute scipy.ndimage.correlate to pin it."""
+    if correlate is None:
+        correlate = _window_sums
     if prior is None:
         prior = img.mean()
     k = 2 * int(ksize) + 1
     weights = np.ones((k, k)) if kernel == "box" else structuring_element(ELLIPSE, k).astype(float)
     count = weights.sum()
     data = img.astype(np.int64) - prior
-    s1 = ndimage.correlate(np.asarray(data, float), weights, mode="constant", cval=0.0)
+    s1 = correlate(np.asarray(data, float), weights)
     if exclude_center:
         s1 = s1 - data
         count -= 1
     mean = s1 / count + prior
     d2 = np.square(np.asarray(data, float))
-    s2 = ndimage.correlate(d2, weights, mode="constant", cval=0.0)
+    s2 = correlate(d2, weights)
     if exclude_center:
         s2 = s2 - d2
     var = (s2 - s1 ** 2 / count) / (count - 1)
     return mean, var
+
+
+def image_statistics_scipy(img, kernel="box", ksize=5, prior=None, exclude_center=False):
+    from scipy import ndimage
+    return image_statistics(img, kernel, ksize, prior, exclude_center,
+                            correlate=lambda d, wgt: ndimage.correlate(d, wgt, mode="constant", cval=0.0))
 
 
 def chain_u8(frames, sigma, thresh, morph_ksize=0, connectivity=4, mean=None, n_seen=0,

@@ -776,3 +776,65 @@ double vao_contour_area(const int32_t *pts, int n)
     }
     return fabs(a00 * 0.5);
 }
+
+/* ------------------------------------------------------------------------------------
+ * A9  cv2.moments(contour)  -- regionprops(contour=...), video/analysis/image.py:355, and
+ *     Polygon.moments, video/analysis/shapes.py:527-533 (float32 points there).
+ * Restates OpenCV's contourMoments (modules/imgproc/src/moments.cpp): Green's theorem over the
+ * closed polygon, ten double accumulators updated sequentially from point lpt-1 -> 0 -> 1 ...,
+ * then the constant factors 1/2, 1/6, 1/12, 1/24, 1/20, 1/60 carrying the sign of a00 so that
+ * m00 >= 0 for either orientation; |a00| <= FLT_EPSILON leaves every moment 0.
+ * pts: n points (x, y), int32 when is_float == 0, float32 otherwise.  out[10] = m00 m10 m01 m20
+ * m11 m02 m30 m21 m12 m03 (complete with vao_complete_moments).
+ * ---------------------------------------------------------------------------------- */
+void vao_contour_moments(const void *pts, int n, int is_float, double *out)
+{
+    const int32_t *pi = (const int32_t *)pts;
+    const float *pf = (const float *)pts;
+    for (int k = 0; k < 10; k++)
+        out[k] = 0.0;
+    if (n == 0)
+        return;
+    double a00 = 0, a10 = 0, a01 = 0, a20 = 0, a11 = 0, a02 = 0, a30 = 0, a21 = 0, a12 = 0, a03 = 0;
+    double xi_1 = is_float ? (double)pf[2 * (n - 1)] : (double)pi[2 * (n - 1)];
+    double yi_1 = is_float ? (double)pf[2 * (n - 1) + 1] : (double)pi[2 * (n - 1) + 1];
+    double xi_12 = xi_1 * xi_1, yi_12 = yi_1 * yi_1;
+    for (int i = 0; i < n; i++) {
+        double xi = is_float ? (double)pf[2 * i] : (double)pi[2 * i];
+        double yi = is_float ? (double)pf[2 * i + 1] : (double)pi[2 * i + 1];
+        double xi2 = xi * xi, yi2 = yi * yi;
+        double dxy = xi_1 * yi - xi * yi_1;
+        double xii_1 = xi_1 + xi, yii_1 = yi_1 + yi;
+        a00 += dxy;
+        a10 += dxy * xii_1;
+        a01 += dxy * yii_1;
+        a20 += dxy * (xi_1 * xii_1 + xi2);
+        a11 += dxy * (xi_1 * (yii_1 + yi_1) + xi * (yii_1 + yi));
+        a02 += dxy * (yi_1 * yii_1 + yi2);
+        a30 += dxy * xii_1 * (xi_12 + xi2);
+        a03 += dxy * yii_1 * (yi_12 + yi2);
+        a21 += dxy * (xi_12 * (3 * yi_1 + yi) + 2 * xi * xi_1 * yii_1 + xi2 * (yi_1 + 3 * yi));
+        a12 += dxy * (yi_12 * (3 * xi_1 + xi) + 2 * yi * yi_1 * xii_1 + yi2 * (xi_1 + 3 * xi));
+        xi_1 = xi;
+        yi_1 = yi;
+        xi_12 = xi2;
+        yi_12 = yi2;
+    }
+    if (fabs(a00) > 1.1920928955078125e-07 /* FLT_EPSILON */) {
+        double s = a00 > 0 ? 1.0 : -1.0;
+        double db1_2 = s * 0.5, db1_6 = s * 0.16666666666666666666666666666667;
+        double db1_12 = s * 0.083333333333333333333333333333333;
+        double db1_24 = s * 0.041666666666666666666666666666667, db1_20 = s * 0.05;
+        double db1_60 = s * 0.016666666666666666666666666666667;
+        out[0] = a00 * db1_2;
+        out[1] = a10 * db1_6;
+        out[2] = a01 * db1_6;
+        out[3] = a20 * db1_12;
+        out[4] = a11 * db1_24;
+        out[5] = a02 * db1_12;
+        out[6] = a30 * db1_20;
+        out[7] = a21 * db1_60;
+        out[8] = a12 * db1_60;
+        out[9] = a03 * db1_20;
+    }
+}

@@ -1,0 +1,224 @@
+"""GPU: every BASELINE.json configuration at its full frame size, through `va_pipeline_run`.
+
+The oracle cannot run a whole batch at these sizes in seconds, so each configuration is checked by
+  * exact oracle comparisons on crops (background model and blur are local up to the blur radius;
+    crops that touch the image border check the BORDER_REFLECT_101 handling on that side),
+  * exact oracle comparisons of whole frames for the non-local stages (threshold, morphology,
+    labelling) fed with the GPU's own blurred frames,
+  * size-independent properties over the full batch.
+cfg#2: 1080p, bg-sub + sigma=5 + threshold (no morphology, no labelling: the mask-only path)
+cfg#4: 3840x2160, full chain, one rank's share of the batch (128 frames), both labelling paths
+cfg#5: 1920x1080x3 float32, EMA background + sigma=9 blur, batch 256
+plus a bounded, seeded slice of tools/stress_parity.py / tools/stress_f32.py.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _engine(**kw):
+    from video import _hip
+    from video.engine import FrameEngine
+    _hip.lib()                      # loud failure without the extension / a GPU
+    return FrameEngine(**kw)
+
+
+def _moving_blob_clip(n, h, w, seed, nblobs, salt, noise_tiles=8):
+    """SURVEY.md 8(d) generator, cheap enough for full-size batches: static N(100,10) background,
+    N(0,4) noise (a few tiles cycled), moving filled discs (+60), optional salt noise"""
+    rng = np.random.default_rng(seed)
+    base = np.clip(rng.normal(100, 10, (h, w)), 0, 255).astype(np.float32)
+    noise = rng.normal(0, 4, (noise_tiles, h, w)).astype(np.float32)
+    yy, xx = np.mgrid[:h, :w]
+    cx0, cy0 = rng.uniform(0, w, nblobs), rng.uniform(0, h, nblobs)
+    vx, vy = rng.uniform(-3, 3, nblobs), rng.uniform(-3, 3, nblobs)
+    rad = rng.uniform(8, 60, nblobs)
+    clip = np.empty((n, h, w), np.uint8)
+    for t in range(n):
+        f = base + noise[t % noise_tiles]
+        for k in range(nblobs):
+            x0, y0, r = int(cx0[k] + vx[k] * t), int(cy0[k] + vy[k] * t), int(rad[k])
+            ya, yb, xa, xb = max(0, y0 - r), min(h, y0 + r + 1), max(0, x0 - r), min(w, x0 + r + 1)
+            if ya < yb and xa < xb:
+                sub = f[ya:yb, xa:xb]
+                sub[(xx[ya:yb, xa:xb] - x0) ** 2 + (yy[ya:yb, xa:xb] - y0) ** 2 <= r * r] += 60
+        if salt:
+            sy = rng.integers(0, h, int(salt * h * w))
+            sx = rng.integers(0, w, int(salt * h * w))
+            f[sy, sx] = 255
+        clip[t] = np.clip(f, 0, 255).astype(np.uint8)
+    return clip
+
+
+def _check_bg_blur_crops(oracle, clip, filtered, state, sigma, radius, size=96):
+    """running mean + emitted difference + blur on crops, exact.  A crop's blur is exact wherever
+    the window does not cross one of the crop's INNER edges; edges that coincide with the image
+    border are exact as well (the oracle reflects there exactly like the full image)."""
+    n, h, w = clip.shape
+    for (ya, xa) in ((0, 0), (0, w - size), (h - size, 0), (h - size, w - size),
+                     (h // 2 - 7, w // 2 + 5), (0, w // 3), (h - size, w // 3), (h // 3, 0), (h // 3, w - size)):
+        crop = np.ascontiguousarray(clip[:, ya:ya + size, xa:xa + size])
+        rd, rm = oracle.bg_mean_u8(crop)
+        assert np.array_equal(state[ya:ya + size, xa:xa + size], rm), (ya, xa)
+        blur = oracle.gaussian_u8(rd, sigma)
+        y0 = 0 if ya == 0 else radius
+        y1 = size if ya + size == h else size - radius
+        x0 = 0 if xa == 0 else radius
+        x1 = size if xa + size == w else size - radius
+        assert np.array_equal(filtered[:, ya + y0:ya + y1, xa + x0:xa + x1], blur[:, y0:y1, x0:x1]), (ya, xa)
+
+
+def test_cfg2_1080p_blur_threshold_mask_only(oracle):
+    """BASELINE.json configs[1]: 1920x1080 uint8, batch 256, bg-sub + sigma=5 + threshold."""
+    n, h, w = 256, 1080, 1920
+    clip = _moving_blob_clip(n, h, w, seed=2, nblobs=40, salt=0.0)
+    eng = _engine(size=(w, h), max_batch=n, background="mean", sigma=5.0, thresh=20)
+    assert "mfma" in eng.description
+    mask_only = eng.run(clip, want=("mask",))["mask"]          # the benchmarked path: no u8 blur output
+    eng.set_background(None, 0)
+    out = eng.run(clip, want=("mask", "filtered"))
+    state, n_seen = eng.get_background()
+    eng.close()
+    assert n_seen == n
+    assert np.array_equal(mask_only, out["mask"])
+    assert np.array_equal(out["mask"], np.where(out["filtered"] > 20, 255, 0).astype(np.uint8))
+    assert 0.001 < (mask_only != 0).mean() < 0.5
+    _check_bg_blur_crops(oracle, clip, out["filtered"], state, 5.0, 15)
+
+
+def test_cfg4_4k_full_chain_both_labelling_paths(oracle):
+    """BASELINE.json configs[3]: 3840x2160 uint8 full chain; one rank's shard of the 1024-frame
+    batch (128 frames) through va_pipeline_run, with the library's labelling choice (per-frame
+    kernel, 4 rows per wave at 4K) and with the chip-wide passes (test hook path 1)."""
+    from video import _hip
+    n, h, w = 128, 2160, 3840
+    clip = _moving_blob_clip(n, h, w, seed=4, nblobs=160, salt=0.002, noise_tiles=4)
+    kw = dict(size=(w, h), max_batch=n, background="mean", sigma=5.0, thresh=20,
+              morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4)
+    eng = _engine(**kw)
+    assert "mfma" in eng.description
+    out = eng.run(clip, want=("filtered", "mask", "labels", "counts"))
+    state, n_seen = eng.get_background()
+    labels, mask, counts, filtered = out["labels"], out["mask"], out["counts"], out["filtered"]
+    # -- properties over the whole shard
+    assert n_seen == n and counts.min() >= 1
+    assert np.array_equal(labels != 0, mask != 0)
+    assert np.array_equal(labels.reshape(n, -1).max(1), counts)
+    for f in range(0, n, 9):
+        assert labels[f].ravel()[np.flatnonzero(labels[f].ravel())[0]] == 1      # raster order
+        assert len(np.unique(labels[f][labels[f] > 0])) == counts[f]             # 1..L all used
+    # -- exact: background + blur on crops (incl. all four borders and corners)
+    _check_bg_blur_crops(oracle, clip, filtered, state, 5.0, 15)
+    # -- exact: whole frames through threshold, close, labelling
+    for f in (1, 77, 127):
+        m = oracle.threshold_u8(filtered[f], 20)
+        m = oracle.morph_u8(oracle.morph_u8(m, oracle.DILATE, oracle.RECT, 5), oracle.ERODE, oracle.RECT, 5)
+        rl, rc = oracle.label(m, 4)
+        assert np.array_equal(mask[f], m) and rc == counts[f] and np.array_equal(labels[f], rl), f
+    # -- the chip-wide labelling passes give the same label maps; so does a counts-only run
+    eng.set_background(None, 0)
+    _hip.check(_hip.lib().va_test_hook_labelling(1, 0))
+    try:
+        out1 = eng.run(clip, want=("labels", "counts"))
+    finally:
+        _hip.check(_hip.lib().va_test_hook_labelling(0, 0))
+    assert np.array_equal(out1["counts"], counts)
+    assert np.array_equal(out1["labels"], labels)
+    eng.set_background(None, 0)
+    assert np.array_equal(eng.run(clip, want=("counts",))["counts"], counts)
+    eng.close()
+
+
+def _f32_clip(n, h, w, c, seed):
+    """SURVEY.md 8(d) cfg#5: U(0,1) noise + a low-frequency sinusoid drifting 0.1 %/frame"""
+    rng = np.random.default_rng(seed)
+    yy = np.arange(h, dtype=np.float32)[:, None, None]
+    xx = np.arange(w, dtype=np.float32)[None, :, None]
+    ph = np.arange(c, dtype=np.float32)[None, None, :]
+    clip = np.empty((n, h, w, c), np.float32)
+    for t in range(n):
+        wave = 0.25 * np.sin(xx * (2 * np.pi / 480) + yy * (2 * np.pi / 270) + ph + 0.001 * t * 2 * np.pi)
+        clip[t] = rng.random((h, w, c), dtype=np.float32) * 0.5 + 0.25 + wave.astype(np.float32)
+    return clip
+
+
+def _check_f32_crops(oracle, clip, out, rate, sigma, radius, frames, size):
+    n, h, w, c = clip.shape
+    for (ya, xa) in ((0, 0), (h - size, w - size), (0, w // 2), (h // 2 - 3, 0), (h // 3, w // 3), (h - size, w // 4)):
+        crop = np.ascontiguousarray(clip[:, ya:ya + size, xa:xa + size])
+        diff, _ = oracle.bg_ema_f32(crop, rate=rate)
+        y0 = 0 if ya == 0 else radius
+        y1 = size if ya + size == h else size - radius
+        x0 = 0 if xa == 0 else radius
+        x1 = size if xa + size == w else size - radius
+        for f in frames:
+            blur = oracle.gaussian_f32(diff[f], sigma, layout="hwc")
+            got = out[f, ya + y0:ya + y1, xa + x0:xa + x1]
+            assert np.array_equal(got.view(np.uint32), blur[y0:y1, x0:x1].view(np.uint32)), (ya, xa, f)
+
+
+def test_cfg5_1080p_f32x3_sigma9_ema(oracle):
+    """BASELINE.json configs[4]: 1920x1080 float32 x 3 channels, batch 256, adaptive (EMA)
+    background + per-channel sigma=9 Gaussian (73 taps) through va_pipeline_run.  Bit patterns
+    against the oracle on crops (interior and all border kinds), whole-batch properties."""
+    n, h, w, c = 256, 1080, 1920, 3
+    rate, sigma, radius = 0.02, 9.0, 36
+    clip = _f32_clip(n, h, w, c, seed=5)
+    eng = _engine(size=(w, h), channels=c, dtype=np.float32, max_batch=n, background="ema",
+                  bg_rate=rate, sigma=sigma)
+    out = eng.run(clip, want=("filtered",))["filtered"]
+    state, n_seen = eng.get_background()
+    assert n_seen == n and out.shape == clip.shape and out.dtype == np.float32
+    # properties: the first frame initialises the model (difference 0 -> blur exactly 0);
+    # everything finite and non-negative (|diff| >= 0, taps > 0); EMA state on crops
+    assert not out[0].any()
+    assert np.isfinite(out).all() and out.min() >= 0.0
+    assert out[1:].max() > 0.01
+    crop = np.ascontiguousarray(clip[:, 500:532, 900:932])
+    _, bg = oracle.bg_ema_f32(crop, rate=rate)
+    assert np.array_equal(state[500:532, 900:932].view(np.uint32), bg.view(np.uint32))
+    _check_f32_crops(oracle, clip, out, rate, sigma, radius, frames=(1, 100, 255), size=112)
+    # splitting the batch must not change a bit (state hand-over between runs)
+    eng.set_background(None, 0)
+    a = eng.run(clip[:100], want=("filtered",))["filtered"]
+    assert np.array_equal(a.view(np.uint32), out[:100].view(np.uint32))
+    b = eng.run(clip[100:130], want=("filtered",))["filtered"]
+    assert np.array_equal(b.view(np.uint32), out[100:130].view(np.uint32))
+    eng.close()
+
+
+def test_stress_slice_fused_chain(oracle):
+    """a bounded, seeded slice of tools/stress_parity.py: random sizes / sigmas / thresholds /
+    morphology chains / connectivities / batch sizes through the fused chain against the oracle"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stress_parity
+    rng = np.random.default_rng(20261004)
+    for case in range(1, 41):
+        ok, desc = stress_parity.run_case(rng, case)
+        assert ok, desc
+
+
+def test_stress_slice_gaussian_f32(oracle):
+    """a bounded, seeded slice of tools/stress_f32.py: bit patterns of the float32 Gaussian"""
+    from video import ops
+    rng = np.random.default_rng(55)
+    for case in range(60):
+        c = int(rng.choice([1, 3]))
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 400))
+        if rng.random() < 0.15:
+            w = int(rng.choice([1920, 1280, 640, 2000]))
+        n = int(rng.integers(1, 4))
+        sigma = float(rng.choice([0.5, 1.0, 2.0, 3.3, 5.0, 9.0, 11.0, 12.5, 15.0]))
+        shape = (n, h, w, c) if c == 3 else (n, h, w)
+        f = (rng.random(shape, dtype=np.float32) * 3 - 1).astype(np.float32)
+        f.flat[::53] = 0.0
+        f.flat[7::131] = -0.0
+        ref = oracle.gaussian_f32(f, sigma)
+        got = ops.gaussian_blur(f, sigma, color=(c == 3))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (shape, sigma)

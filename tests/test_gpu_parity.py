@@ -778,3 +778,111 @@ def test_rccl_gather_counts_single_rank():
     check(L.va_comm_destroy(comm))
     send.free()
     recv.free()
+
+
+def test_two_streams_do_not_share_scratch(oracle):
+    """the stand-alone entry points lease their device scratch per call on the call's own stream
+    (va_api.hip ScratchLease): interleaved calls of different sizes on two streams -- the
+    reference's VideoPreprocessor worker threads, video/io/parallel.py:398-400 -- must not see
+    each other's intermediates (the generic Gaussian keeps its u16 row pass there; the bit-packed
+    morphology both of its masks)"""
+    import ctypes as C
+    import threading
+    from video import _hip
+    from video._hip import DeviceBuffer, check
+    L = _hip.lib()
+    rng = np.random.default_rng(123)
+    a = rng.integers(0, 256, (6, 301, 517), dtype=np.uint8)          # generic path (odd width)
+    b = rng.integers(0, 256, (2, 97, 133, 3), dtype=np.uint8)
+    m = ((rng.random((4, 120, 200)) < 0.4) * 255).astype(np.uint8)
+    ref_a, ref_b = oracle.gaussian_u8(a, 3.0), oracle.gaussian_u8(b, 2.0)
+    ref_m = oracle.morph_u8(m, oracle.DILATE, oracle.RECT, 5)
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    check(L.va_stream_create(C.byref(s1)))
+    check(L.va_stream_create(C.byref(s2)))
+    da, db, dm = DeviceBuffer.from_array(a), DeviceBuffer.from_array(b), DeviceBuffer.from_array(m)
+    oa, ob, om = DeviceBuffer(a.nbytes), DeviceBuffer(b.nbytes), DeviceBuffer(m.nbytes)
+    errors = []
+
+    def worker(stream, jobs):
+        try:
+            for _ in range(20):
+                for fn, args in jobs:
+                    check(fn(*args, stream))
+            check(L.va_stream_sync(stream))
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+
+    t1 = threading.Thread(target=worker, args=(s1, [(L.va_gaussian_u8_generic, (da.ptr, oa.ptr, 6, 301, 517, 1, 3.0))]))
+    t2 = threading.Thread(target=worker, args=(s2, [
+        (L.va_gaussian_u8_generic, (db.ptr, ob.ptr, 2, 97, 133, 3, 2.0)),
+        (L.va_morph_bits_u8, (dm.ptr, om.ptr, 4, 120, 200, _hip.MORPH_DILATE, _hip.SHAPE_RECT, 5))]))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    assert not errors, errors
+    assert np.array_equal(oa.download(a.shape, np.uint8), ref_a)
+    assert np.array_equal(ob.download(b.shape, np.uint8), ref_b)
+    assert np.array_equal(om.download(m.shape, np.uint8), ref_m)
+    for buf in (da, db, dm, oa, ob, om):
+        buf.free()
+    check(L.va_stream_destroy(s1))
+    check(L.va_stream_destroy(s2))
+
+
+def test_pipeline_counts_only_skips_paint(oracle, ccl_mode):
+    """counts without labels/stats: the label image is never painted (va_pipeline_run passes
+    paint=false), on every labelling path, and the counts still match the oracle"""
+    n = 20 if ccl_mode == "chip-wide" else 100
+    clip = _blob_clip(n, 90, 160, seed=31, salt=0.003)
+    _, _, rc, _ = oracle.chain_u8(clip, 2.0, 20, morph_ksize=3, connectivity=8, want_labels=True)
+    eng = _engine(size=(160, 90), max_batch=n, background="mean", sigma=2.0, thresh=20,
+                  morphology=(("dilate", "rect", 3), ("erode", "rect", 3)), connectivity=8, max_labels=8)
+    eng.profile(True)
+    out = eng.run(clip, want=("counts",))
+    stages = eng.stage_times()
+    assert np.array_equal(out["counts"], rc)
+    assert "ccl_paint" not in stages and ("ccl_frame" in stages or "ccl_rank" in stages)
+    eng.set_background(None, 0)
+    out = eng.run(clip, want=("counts", "stats"))          # stats come from the paint pass
+    assert np.array_equal(out["counts"], rc)
+    assert "ccl_paint" in eng.stage_times()
+    eng.close()
+
+
+def test_contour_moments_match_oracle_bit_for_bit(ops, oracle):
+    """A9: cv2.moments(contour) on the GPU (va_contour_moments) against the oracle's restatement
+    of OpenCV's contourMoments -- same float64 bits for int32 and float32 points, either
+    orientation, degenerate contours, long contours at 1080p/4K coordinates (terms above 2^53)"""
+    from video.analysis import image, regions, shapes
+    rng = np.random.default_rng(17)
+    cases = [np.array([[0, 0], [4, 0], [4, 4], [0, 4]], np.int32),
+             np.array([[0, 0], [4, 0], [4, 4], [0, 4]], np.int32)[::-1],
+             np.array([[3, 3]], np.int32), np.array([[1, 1], [5, 1]], np.int32),
+             np.array([[0, 0], [6, 0], [0, 3]], np.float32),
+             (rng.random((500, 2)) * (3840, 2160)).astype(np.float32),
+             rng.integers(0, 3840, (3000, 2)).astype(np.int32),
+             np.array([[[10, 20]], [[10, 29]], [[49, 29]], [[49, 20]]], np.float64)]
+    th = np.linspace(0, 2 * np.pi, 700, endpoint=False)
+    cases.append(np.stack([1900 + 1800 * np.cos(th), 1080 + 1000 * np.sin(th)], 1).round().astype(np.int32))
+    for c in cases:
+        ref = oracle.contour_moments(c)
+        got = image.contour_moments(c)
+        assert set(got) == set(ref)
+        for k, v in ref.items():
+            assert np.float64(got[k]).tobytes() == np.float64(v).tobytes(), (k, got[k], v, c.shape)
+    # through the analysis API: contour of the largest region -> regionprops / Polygon
+    yy, xx = np.mgrid[:300, :400]
+    m = (((xx - 150) / 90.0) ** 2 + ((yy - 140) / 60.0) ** 2 <= 1).astype(np.uint8)
+    m[200:260, 300:380] = 1
+    contour = regions.get_contour_from_largest_region(m)
+    ref = oracle.contour_moments(np.asarray(contour, np.float32))
+    props = image.regionprops(contour=contour)
+    poly = shapes.Polygon(contour)
+    for k, v in ref.items():
+        assert props.moments[k] == v and poly.moments[k] == v, k
+    assert props.area == ref["m00"] and 0 < poly.eccentricity < 1
+    rp = image.regionprops(mask=regions.get_largest_region(m))         # raster moments of the same blob
+    assert abs(props.centroid[0] - rp.centroid[0]) < 0.5 and abs(props.orientation - rp.orientation) < 0.05
+    # the fused form: moments from the device-resident points of va_largest_contour
+    pts, area, count, mom = ops.largest_contour(m, moments=True)
+    assert count == 2 and area == ref["m00"]
+    assert np.array_equal(mom, [ref[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03")])

@@ -253,3 +253,63 @@ def test_contours_known_answers_and_properties(golden, oracle):
         filled = ndimage.binary_fill_holes(lab == comp)
         assert np.array_equal(poly, filled)
         assert area <= filled.sum()
+
+
+def test_n2_numpy_oracle_matches_literal_scipy(oracle):
+    """the oracle's detect_peaks / image_statistics are plain NumPy (the GPU box needs no SciPy);
+    here, where SciPy is installed, they are pinned to the literal scipy.ndimage restatements of
+    video/analysis/image.py:131-201, 267-306"""
+    pytest.importorskip("scipy")
+    rng = np.random.default_rng(5)
+    for shape in ((1, 1), (1, 9), (7, 1), (3, 3), (40, 53), (65, 31)):
+        for im in (rng.integers(0, 6, shape, dtype=np.uint8) * rng.integers(0, 2, shape, dtype=np.uint8),
+                   (rng.integers(0, 256, shape) // 32 * 32).astype(np.uint8),
+                   np.zeros(shape, np.uint8), np.full(shape, 9, np.uint8)):
+            for plateaus in (True, False):
+                assert np.array_equal(oracle.detect_peaks(im, plateaus),
+                                      oracle.detect_peaks_scipy(im, plateaus)), (shape, plateaus)
+    img = rng.integers(0, 256, (37, 45), dtype=np.uint8)
+    for kernel in ("box", "ellipse"):
+        for ksize in (1, 2, 5):
+            for excl in (False, True):
+                for prior in (0, 128, None, 100.5):
+                    m, v = oracle.image_statistics(img, kernel, ksize, prior, excl)
+                    rm, rv = oracle.image_statistics_scipy(img, kernel, ksize, prior, excl)
+                    if prior in (0, 128):
+                        assert np.array_equal(m, rm) and np.array_equal(v, rv)
+                    else:
+                        assert np.allclose(m, rm, rtol=1e-13, atol=1e-10)
+                        assert np.allclose(v, rv, rtol=1e-10, atol=1e-7)
+
+
+def test_contour_moments_known_answers(oracle):
+    """cv2.moments(contour) restatement (video/analysis/image.py:355, shapes.py:533): analytic
+    polygon moments of rectangles / triangles, orientation independence, degenerate contours,
+    and agreement with the raster moments' derived quantities in the limit of large shapes"""
+    sq = np.array([[0, 0], [4, 0], [4, 4], [0, 4]], np.int32)
+    m = oracle.contour_moments(sq)
+    assert (m["m00"], m["m10"], m["m01"], m["m11"], m["m30"]) == (16.0, 32.0, 32.0, 64.0, 256.0)
+    assert abs(m["m20"] - 256 / 3) < 1e-12 and abs(m["m21"] - 512 / 3) < 1e-12
+    assert abs(m["mu20"] - 64 / 3) < 1e-12 and m["mu11"] == 0.0
+    assert abs(m["nu20"] - (64 / 3) / 256) < 1e-15
+    r = oracle.contour_moments(sq[::-1])                       # clockwise: same moments
+    assert all(r[k] == m[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02"))
+    tri = np.array([[0, 0], [6, 0], [0, 3]], np.float32)       # area 9, centroid (2, 1)
+    t = oracle.contour_moments(tri)
+    assert t["m00"] == 9.0 and t["m10"] == 18.0 and t["m01"] == 9.0
+    assert abs(t["m20"] - 54.0) < 1e-12 and abs(t["m02"] - 13.5) < 1e-12 and abs(t["m11"] - 13.5) < 1e-12
+    for degenerate in (np.array([[3, 3]], np.int32), np.array([[1, 1], [5, 1]], np.int32),
+                       np.array([[0, 0], [2, 2], [4, 4]], np.int32)):
+        assert all(v == 0.0 for v in oracle.contour_moments(degenerate).values())
+    # (N,1,2) layout of cv2.findContours, float dtype = float32 points, shifted rectangle
+    rect = np.array([[[10, 20]], [[10, 29]], [[49, 29]], [[49, 20]]], np.float64)
+    q = oracle.contour_moments(rect)
+    assert q["m00"] == 39.0 * 9.0 and q["m10"] / q["m00"] == 29.5 and q["m01"] / q["m00"] == 24.5
+    # contour of a filled raster region: polygon through the boundary pixel centres
+    yy, xx = np.mgrid[:80, :90]
+    disc = ((xx - 45) ** 2 + (yy - 38) ** 2 <= 30 ** 2).astype(np.uint8)
+    c = oracle.get_contour_from_largest_region(disc)
+    cm = oracle.contour_moments(np.asarray(c, np.int32))
+    assert abs(cm["m00"] - oracle.contour_area(np.asarray(c, np.int32))) < 1e-9
+    assert abs(cm["m10"] / cm["m00"] - 45) < 1e-9 and abs(cm["m01"] / cm["m00"] - 38) < 1e-9
+    assert abs(cm["mu20"] - cm["mu02"]) / cm["mu20"] < 1e-9 and abs(cm["mu11"]) < 1e-6

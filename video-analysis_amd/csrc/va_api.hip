@@ -24,29 +24,52 @@ void set_error(const char *fmt, ...)
 }
 const char *get_error() { return g_err; }
 
-// grow-only device scratch shared by the stand-alone entry points (stream-ordered use from one
-// stream at a time, like the reference's single-threaded pull model, video/io/base.py:207-223)
-static std::mutex g_scratch_mu;
-static void *g_scratch = nullptr;
-static size_t g_scratch_bytes = 0;
-
-static int get_scratch(size_t bytes, void **out)
-{
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (bytes > g_scratch_bytes) {
-        if (g_scratch) {
-            VA_HIP(hipDeviceSynchronize());
-            VA_HIP(hipFree(g_scratch));
-            g_scratch = nullptr;
-            g_scratch_bytes = 0;
+// Device scratch of the stand-alone entry points: one stream-ordered lease per call
+// (hipMallocAsync / hipFreeAsync on the call's own stream, served by the device's default memory
+// pool, whose release threshold va_init raises so that the pool keeps its pages between calls).
+// Nothing is shared between calls, so the reference's concurrent callers -- VideoPreprocessor's
+// worker threads, video/io/parallel.py:398-400 -- may use one stream each without seeing each
+// other's intermediates, and no call synchronises the device.
+struct ScratchLease {
+    void *ptr = nullptr;
+    hipStream_t st = nullptr;
+    int acquire(size_t bytes, hipStream_t stream)
+    {
+        st = stream;
+        hipError_t e = hipMallocAsync(&ptr, bytes ? bytes : 256, st);
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            set_error("scratch: hipMallocAsync(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return VA_ERR_NOMEM;
         }
-        size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-        VA_HIP(hipMalloc(&g_scratch, want));
-        g_scratch_bytes = want;
+        return VA_OK;
     }
-    *out = g_scratch;
+    ~ScratchLease()
+    {
+        if (ptr)
+            (void)hipFreeAsync(ptr, st);      // ordered after the kernels enqueued on st
+    }
+};
+
+// One device per process (one process per GPU): va_init records it, and every
+// entry point that allocates or launches selects it for the calling thread first -- hipSetDevice
+// is per thread, so a worker thread that never called va_init would otherwise run on device 0.
+static int g_device = -1;
+static thread_local int tl_device = -1;
+int enter_device()
+{
+    if (g_device >= 0 && tl_device != g_device) {
+        VA_HIP(hipSetDevice(g_device));
+        tl_device = g_device;
+    }
     return VA_OK;
 }
+#define VA_ENTER()                   \
+    do {                             \
+        int _rc = va::enter_device(); \
+        if (_rc)                     \
+            return _rc;              \
+    } while (0)
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) & ~(a - 1); }
 
@@ -103,13 +126,23 @@ int va_init(int device)
         return VA_ERR_NODEV;
     }
     VA_REQUIRE(device >= 0 && device < n, "va_init: device %d out of range [0,%d)", device, n);
+    VA_REQUIRE(g_device < 0 || g_device == device,
+               "va_init: this process already runs on device %d (one device per process)", g_device);
     VA_HIP(hipSetDevice(device));
     VA_HIP(hipFree(nullptr));  // force context creation
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t keep = ~(uint64_t)0;   // keep freed scratch in the pool instead of unmapping it
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    g_device = device;
+    tl_device = device;
     return VA_OK;
 }
 
 int va_malloc(void **dev_ptr, size_t bytes)
 {
+    VA_ENTER();
     VA_REQUIRE(dev_ptr, "va_malloc: NULL out pointer");
     *dev_ptr = nullptr;
     if (bytes == 0)
@@ -119,12 +152,14 @@ int va_malloc(void **dev_ptr, size_t bytes)
 }
 int va_free(void *dev_ptr)
 {
+    VA_ENTER();
     if (dev_ptr)
         VA_HIP(hipFree(dev_ptr));
     return VA_OK;
 }
 int va_host_alloc(void **host_ptr, size_t bytes)
 {
+    VA_ENTER();
     VA_REQUIRE(host_ptr, "va_host_alloc: NULL out pointer");
     *host_ptr = nullptr;
     if (bytes == 0)
@@ -134,42 +169,49 @@ int va_host_alloc(void **host_ptr, size_t bytes)
 }
 int va_host_free(void *host_ptr)
 {
+    VA_ENTER();
     if (host_ptr)
         VA_HIP(hipHostFree(host_ptr));
     return VA_OK;
 }
 int va_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
+    VA_ENTER();
     if (bytes)
         VA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
     return VA_OK;
 }
 int va_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
 {
+    VA_ENTER();
     if (bytes)
         VA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
     return VA_OK;
 }
 int va_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
 {
+    VA_ENTER();
     if (bytes)
         VA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
     return VA_OK;
 }
 int va_memset(void *dst, int value, size_t bytes, void *stream)
 {
+    VA_ENTER();
     if (bytes)
         VA_HIP(hipMemsetAsync(dst, value, bytes, as_stream(stream)));
     return VA_OK;
 }
 int va_stream_sync(void *stream)
 {
+    VA_ENTER();
     VA_HIP(hipStreamSynchronize(as_stream(stream)));
     return VA_OK;
 }
 
 int va_stream_create(void **stream_out)
 {
+    VA_ENTER();
     VA_REQUIRE(stream_out, "va_stream_create: NULL argument");
     hipStream_t s;
     VA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -178,12 +220,14 @@ int va_stream_create(void **stream_out)
 }
 int va_stream_destroy(void *stream)
 {
+    VA_ENTER();
     if (stream)
         VA_HIP(hipStreamDestroy(as_stream(stream)));
     return VA_OK;
 }
 int va_event_create(void **event_out)
 {
+    VA_ENTER();
     VA_REQUIRE(event_out, "va_event_create: NULL argument");
     hipEvent_t e;
     VA_HIP(hipEventCreate(&e));
@@ -192,30 +236,35 @@ int va_event_create(void **event_out)
 }
 int va_event_destroy(void *event)
 {
+    VA_ENTER();
     if (event)
         VA_HIP(hipEventDestroy((hipEvent_t)event));
     return VA_OK;
 }
 int va_event_record(void *event, void *stream)
 {
+    VA_ENTER();
     VA_REQUIRE(event, "va_event_record: NULL event");
     VA_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
     return VA_OK;
 }
 int va_stream_wait_event(void *stream, void *event)
 {
+    VA_ENTER();
     VA_REQUIRE(event, "va_stream_wait_event: NULL event");
     VA_HIP(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
     return VA_OK;
 }
 int va_event_sync(void *event)
 {
+    VA_ENTER();
     VA_REQUIRE(event, "va_event_sync: NULL event");
     VA_HIP(hipEventSynchronize((hipEvent_t)event));
     return VA_OK;
 }
 int va_event_elapsed_ms(void *start_event, void *stop_event, float *ms_out)
 {
+    VA_ENTER();
     VA_REQUIRE(start_event && stop_event && ms_out, "va_event_elapsed_ms: NULL argument");
     VA_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)start_event, (hipEvent_t)stop_event));
     return VA_OK;
@@ -284,6 +333,9 @@ static int blur_u8_planes(const uint8_t *src, uint8_t *dst, int n, int h, int w,
 int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma,
                    void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_gaussian_u8: frames above 2^29 pixels are not supported");
     VA_REQUIRE(src && dst && src != dst, "va_gaussian_u8: src/dst must be distinct non-NULL");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "va_gaussian_u8: bad shape (%d,%d,%d,%d)", n, h,
                w, c);
@@ -298,40 +350,46 @@ int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
         if (gauss_fused_supported(w, h, t))
             return launch_gauss_fused_u8(src, dst, nullptr, -1, n, h, w, t, as_stream(stream));
     }
-    void *scratch;
+    ScratchLease scratch;
     if (const int wp = planes_width(h, w, c, t)) {
-        rc = get_scratch(planes_scratch_bytes(n, h, wp, c), &scratch);
+        rc = scratch.acquire(planes_scratch_bytes(n, h, wp, c), as_stream(stream));
         if (rc)
             return rc;
-        return blur_u8_planes(src, dst, n, h, w, wp, c, t, scratch, as_stream(stream));
+        return blur_u8_planes(src, dst, n, h, w, wp, c, t, scratch.ptr, as_stream(stream));
     }
-    rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);
+    rc = scratch.acquire((size_t)n * h * w * c * sizeof(uint16_t), as_stream(stream));
     if (rc)
         return rc;
-    return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch, n, h, w, c, t, as_stream(stream));
+    return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch.ptr, n, h, w, c, t, as_stream(stream));
 }
 
 // test hook: force the generic two-pass implementation
 int va_gaussian_u8_generic(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
                            double sigma, void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_gaussian_u8_generic: frames above 2^29 pixels are not supported");
     VA_REQUIRE(src && dst && src != dst, "va_gaussian_u8_generic: bad pointers");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "va_gaussian_u8_generic: bad shape");
     TapsQ8 t;
     int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
     if (rc)
         return rc;
-    void *scratch;
-    rc = get_scratch((size_t)n * h * w * c * sizeof(uint16_t), &scratch);
+    ScratchLease scratch;
+    rc = scratch.acquire((size_t)n * h * w * c * sizeof(uint16_t), as_stream(stream));
     if (rc)
         return rc;
-    return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch, n, h, w, c, t, as_stream(stream));
+    return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch.ptr, n, h, w, c, t, as_stream(stream));
 }
 
 // test hook: force the LDS/VALU (dot4/dot2) fused implementation
 int va_gaussian_u8_valu(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma,
                         void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_gaussian_u8_valu: frames above 2^29 pixels are not supported");
     VA_REQUIRE(src && dst && src != dst, "va_gaussian_u8_valu: bad pointers");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c == 1, "va_gaussian_u8_valu: bad shape");
     TapsQ8 t;
@@ -352,6 +410,9 @@ int va_test_hook_labelling(int path, int lds_runs)
 int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, double sigma,
                     void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_gaussian_f32: frames above 2^29 pixels are not supported");
     VA_REQUIRE(src && dst && src != dst, "va_gaussian_f32: src/dst must be distinct non-NULL");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "va_gaussian_f32: bad shape (%d,%d,%d,%d)", n,
                h, w, c);
@@ -359,26 +420,27 @@ int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, do
     int rc = gauss_taps_f32(sigma, &t.ksize, t.t, kMaxTaps);
     if (rc)
         return rc;
-    void *scratch;
-    rc = get_scratch((size_t)n * h * w * c * sizeof(float), &scratch);
+    ScratchLease scratch;
+    rc = scratch.acquire((size_t)n * h * w * c * sizeof(float), as_stream(stream));
     if (rc)
         return rc;
     if (gauss_f32_fast_supported(w, c, t))
-        return launch_gauss_f32_fast(src, dst, (float *)scratch, n, h, w, c, t, as_stream(stream));
-    return launch_gauss_generic_f32(src, dst, (float *)scratch, n, h, w, c, t, as_stream(stream));
+        return launch_gauss_f32_fast(src, dst, (float *)scratch.ptr, n, h, w, c, t, as_stream(stream));
+    return launch_gauss_generic_f32(src, dst, (float *)scratch.ptr, n, h, w, c, t, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------ background
 int va_bg_update(int mode, int dtype, const void *frames, void *diff_out, void *state,
                  int64_t n_seen, double rate, int n, size_t px, void *stream)
 {
+    VA_ENTER();
     double *recip = nullptr;
+    ScratchLease scratch;
     if (mode == VA_BG_MEAN && dtype == VA_U8 && n > 0) {
-        void *scratch;
-        int rc = get_scratch(bg_scratch_bytes(n), &scratch);
+        int rc = scratch.acquire(bg_scratch_bytes(n), as_stream(stream));
         if (rc)
             return rc;
-        recip = (double *)scratch;
+        recip = (double *)scratch.ptr;
     }
     return launch_bg(mode, dtype, frames, diff_out, state, n_seen, rate, n, px, as_stream(stream),
                      recip);
@@ -386,6 +448,7 @@ int va_bg_update(int mode, int dtype, const void *frames, void *diff_out, void *
 int va_welford_u8(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
                   size_t px, void *stream)
 {
+    VA_ENTER();
     return launch_welford(frames, mean, m2, n_seen, n, px, as_stream(stream));
 }
 
@@ -393,25 +456,30 @@ int va_welford_u8(const uint8_t *frames, double *mean, double *m2, int64_t n_see
 int va_time_difference_u8(const uint8_t *a, const uint8_t *b, int16_t *out, size_t count,
                           void *stream)
 {
+    VA_ENTER();
     return launch_time_difference(a, b, out, count, as_stream(stream));
 }
 int va_threshold_u8(const uint8_t *src, uint8_t *dst, size_t count, int thresh, int maxval,
                     void *stream)
 {
+    VA_ENTER();
     return launch_threshold_u8(src, dst, count, thresh, maxval, as_stream(stream));
 }
 int va_mono_mean_u8(const uint8_t *src, uint8_t *dst, size_t pixels, void *stream)
 {
+    VA_ENTER();
     return launch_mono_mean(src, dst, pixels, as_stream(stream));
 }
 int va_normalize_u8(const uint8_t *src, uint8_t *dst, size_t count, double fmin, double fmax,
                     double alpha, double tmin, void *stream)
 {
+    VA_ENTER();
     return launch_normalize_u8(src, dst, count, fmin, fmax, alpha, tmin, as_stream(stream));
 }
 
 int va_rot90(const void *src, void *dst, int n, int h, int w, int elem_bytes, int k, void *stream)
 {
+    VA_ENTER();
     return launch_rot90(src, dst, n, h, w, elem_bytes, k, as_stream(stream));
 }
 
@@ -419,6 +487,9 @@ int va_rot90(const void *src, void *dst, int n, int h, int w, int elem_bytes, in
 int va_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op, int shape,
                 int ksize, void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_morph_u8: frames above 2^29 pixels are not supported");
     VA_REQUIRE(src && dst && src != dst, "va_morph_u8: src/dst must be distinct non-NULL");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_morph_u8: bad shape (%d,%d,%d)", n, h, w);
     VA_REQUIRE(op == VA_MORPH_ERODE || op == VA_MORPH_DILATE, "va_morph_u8: bad op %d", op);
@@ -434,6 +505,9 @@ int va_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op, i
 int va_morph_bits_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op, int shape,
                      int ksize, void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_morph_bits_u8: frames above 2^29 pixels are not supported");
     VA_REQUIRE(src && dst, "va_morph_bits_u8: NULL argument");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_morph_bits_u8: bad shape");
     RowSpans se;
@@ -441,12 +515,12 @@ int va_morph_bits_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int 
     if (rc)
         return rc;
     size_t words = align_up((size_t)n * h * words_per_row(w) * sizeof(uint32_t));
-    void *scratch;
-    rc = get_scratch(2 * words, &scratch);
+    hipStream_t st = as_stream(stream);
+    ScratchLease scratch;
+    rc = scratch.acquire(2 * words, st);
     if (rc)
         return rc;
-    uint32_t *b0 = (uint32_t *)scratch, *b1 = (uint32_t *)((char *)scratch + words);
-    hipStream_t st = as_stream(stream);
+    uint32_t *b0 = (uint32_t *)scratch.ptr, *b1 = (uint32_t *)((char *)scratch.ptr + words);
     if ((rc = launch_pack_bits(src, b0, n, h, w, 0, st)))
         return rc;
     if ((rc = launch_morph_bits(b0, b1, n, h, w, op, se, st)))
@@ -465,6 +539,9 @@ size_t va_label_workspace_bytes(int n, int h, int w)
 int va_label_i32(const uint8_t *mask, int32_t *labels, int32_t *counts, int n, int h, int w,
                  int connectivity, void *workspace, size_t workspace_bytes, void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_label_i32: frames above 2^29 pixels are not supported");
     VA_REQUIRE(mask && labels && counts && workspace, "va_label_i32: NULL argument");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_label_i32: bad shape (%d,%d,%d)", n, h, w);
     VA_REQUIRE(workspace_bytes >= va_label_workspace_bytes(n, h, w),
@@ -485,6 +562,7 @@ int va_label_i32(const uint8_t *mask, int32_t *labels, int32_t *counts, int n, i
 int va_moments_i64(const int32_t *labels, int n, int h, int w, int max_labels, int64_t *stats,
                    void *stream)
 {
+    VA_ENTER();
     VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_moments_i64: bad shape (%d,%d,%d)", n, h, w);
     return launch_stats_from_labels(labels, n, h, w, max_labels, stats, as_stream(stream));
 }
@@ -493,6 +571,7 @@ int va_largest_region(const int32_t *labels, const int32_t *counts, const int64_
                       int h, int w, int max_labels, int32_t *largest, int64_t *largest_area,
                       uint8_t *mask_out, void *stream)
 {
+    VA_ENTER();
     VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_largest_region: bad shape (%d,%d,%d)", n, h, w);
     return launch_largest_region(labels, counts, stats, n, h, w, max_labels, largest, largest_area,
                                  mask_out, as_stream(stream));
@@ -502,6 +581,9 @@ int va_largest_region(const int32_t *labels, const int32_t *counts, const int64_
 int va_detect_peaks_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int include_plateaus,
                        void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_detect_peaks_u8: frames above 2^29 pixels are not supported");
     VA_REQUIRE(src && dst && src != dst, "va_detect_peaks_u8: bad pointers");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_detect_peaks_u8: bad shape");
     return launch_detect_peaks(src, dst, n, h, w, include_plateaus, as_stream(stream));
@@ -512,32 +594,50 @@ int va_mask_thinning_u8(uint8_t *img, uint8_t *scratch, uint8_t *skel, int h, in
 {
     VA_REQUIRE(img && scratch && skel, "va_mask_thinning_u8: NULL argument");
     VA_REQUIRE(h > 0 && w > 0, "va_mask_thinning_u8: bad shape");
+    VA_ENTER();
     hipStream_t st = as_stream(stream);
-    void *cnt_dev;
-    int rc = get_scratch(256, &cnt_dev);
-    if (rc)
-        return rc;
-    VA_HIP(hipMemsetAsync(skel, 0, (size_t)h * w, st));
-    uint8_t *cur = img, *nxt = scratch;
-    int it = 0;
     // a 3x3-cross erosion empties any mask within min(h,w)/2 + 1 steps, except one that fills the
     // frame (the border never wins): the reference would loop forever there, we stop
     const int max_it = (h < w ? h : w) / 2 + 2;
-    for (;; it++) {
-        rc = launch_thinning_step(cur, nxt, skel, 1, h, w, (unsigned long long *)cnt_dev, st);
-        if (rc)
-            return rc;
-        unsigned long long nz = 0;
-        VA_HIP(hipMemcpyAsync(&nz, cnt_dev, sizeof(nz), hipMemcpyDeviceToHost, st));
+    // One counter of surviving pixels per iteration; the exit condition is read back once per
+    // kCheck iterations (steps enqueued past the emptying one see an empty image and change
+    // nothing: eroded = temp = 0, skeleton |= 0), so the host waits ceil(iterations / kCheck)
+    // times instead of once per step.
+    const int kCheck = 16;
+    const int total_it = max_it + 1;
+    ScratchLease cnt;
+    int rc = cnt.acquire(sizeof(unsigned long long) * (size_t)total_it, st);
+    if (rc)
+        return rc;
+    unsigned long long *cnt_dev = (unsigned long long *)cnt.ptr;
+    VA_HIP(hipMemsetAsync(cnt_dev, 0, sizeof(unsigned long long) * (size_t)total_it, st));
+    VA_HIP(hipMemsetAsync(skel, 0, (size_t)h * w, st));
+    uint8_t *cur = img, *nxt = scratch;
+    unsigned long long host_cnt[kCheck];
+    int done_it = -1;
+    for (int it0 = 0; it0 < total_it && done_it < 0; it0 += kCheck) {
+        const int k = (total_it - it0 < kCheck) ? total_it - it0 : kCheck;
+        for (int j = 0; j < k; j++) {
+            rc = launch_thinning_step(cur, nxt, skel, 1, h, w, cnt_dev + it0 + j, st);
+            if (rc)
+                return rc;
+            uint8_t *t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        VA_HIP(hipMemcpyAsync(host_cnt, cnt_dev + it0, sizeof(unsigned long long) * (size_t)k,
+                              hipMemcpyDeviceToHost, st));
         VA_HIP(hipStreamSynchronize(st));
-        uint8_t *t = cur;
-        cur = nxt;
-        nxt = t;
-        if (nz == 0 || it >= max_it)
-            break;
+        for (int j = 0; j < k; j++)
+            if (host_cnt[j] == 0) {
+                done_it = it0 + j;
+                break;
+            }
     }
+    if (done_it < 0)
+        done_it = max_it;
     if (iterations_out)
-        *iterations_out = it + 1;
+        *iterations_out = done_it + 1;
     return VA_OK;
 }
 
@@ -545,6 +645,9 @@ int va_image_statistics_u8(const uint8_t *src, double *mean_out, double *var_out
                            int w, int kernel, int ksize, double prior, int exclude_center,
                            void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_image_statistics_u8: frames above 2^29 pixels are not supported");
     VA_REQUIRE(src && mean_out, "va_image_statistics_u8: NULL argument");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0 && ksize >= 0, "va_image_statistics_u8: bad shape");
     VA_REQUIRE(kernel == 0 || kernel == 1, "va_image_statistics_u8: kernel must be 0 (box) or 1 (ellipse)");
@@ -569,6 +672,9 @@ int va_largest_contour(const uint8_t *mask, int n, int h, int w, int32_t *points
                        int32_t *npoints, double *area, int32_t *ncomponents, void *workspace,
                        size_t workspace_bytes, void *stream)
 {
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_largest_contour: frames above 2^29 pixels are not supported");
     VA_REQUIRE(mask && points && npoints && ncomponents && workspace, "va_largest_contour: NULL argument");
     VA_REQUIRE(n >= 0 && h > 0 && w > 0 && max_points > 0, "va_largest_contour: bad shape");
     VA_REQUIRE(workspace_bytes >= va_contour_workspace_bytes(n, h, w),
@@ -595,6 +701,17 @@ int va_largest_contour(const uint8_t *mask, int n, int h, int w, int32_t *points
     return launch_largest_contour(bits, forest, n, h, w, keys, points, max_points, npoints, area, st);
 }
 
+int va_contour_moments(const void *points, const int32_t *npoints, int n, int max_points,
+                       int is_float, double *moments_out, void *stream)
+{
+    VA_ENTER();
+    VA_REQUIRE(points && moments_out, "va_contour_moments: NULL argument");
+    VA_REQUIRE(n >= 0 && max_points > 0, "va_contour_moments: bad shape (%d contours, %d points)", n,
+               max_points);
+    return launch_contour_moments(points, npoints, n, max_points, is_float, moments_out,
+                                  as_stream(stream));
+}
+
 // ------------------------------------------------------------------------------ pipeline
 static int pipeline_free(va_pipeline *p)
 {
@@ -615,6 +732,7 @@ static int pipeline_free(va_pipeline *p)
 
 int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
 {
+    VA_ENTER();
     VA_REQUIRE(cfg && out, "va_pipeline_create: NULL argument");
     *out = nullptr;
     VA_REQUIRE(cfg->struct_size == (int32_t)sizeof(va_config),
@@ -643,8 +761,9 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
     else
         VA_REQUIRE(cfg->morph_count == 0 && cfg->connectivity == 0,
                    "va_pipeline_create: morphology/labelling need a threshold (thresh >= 0)");
-    VA_REQUIRE((size_t)cfg->width * cfg->height < ((size_t)1 << 31),
-               "va_pipeline_create: frame too large");
+    VA_REQUIRE((size_t)cfg->width * cfg->height < kMaxFramePixels,
+               "va_pipeline_create: frames of %dx%d exceed the supported 2^29 pixels (the kernels'"
+               " 32-bit buffer descriptors address h*w*4 bytes)", cfg->width, cfg->height);
 
     va_pipeline *p = new (std::nothrow) va_pipeline();
     if (!p) {
@@ -729,6 +848,10 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
             p->ccl_ws_bytes = ccl_rows_workspace_bytes(cfg->max_batch, cfg->height);
             PIPE_MALLOC(p->ccl_ws, p->ccl_ws_bytes);
             PIPE_MALLOC(p->counts_scratch, align_up(nb * sizeof(int32_t)));
+            // forest / label scratch for runs that do not ask for the label image (counts only:
+            // sparse forest words, never painted; stats only: painted here).  Allocated now so
+            // that an out-of-memory shows at create time and no run ever calls hipMalloc.
+            PIPE_MALLOC(p->labels_scratch, nb * p->frame_px * sizeof(int32_t));
         }
     }
     snprintf(p->desc, sizeof(p->desc), "bg=%d gauss=%s(ksize=%d) thresh=%d morph=%d ccl=%d",
@@ -749,6 +872,7 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
 
 int va_pipeline_destroy(va_pipeline_t *p)
 {
+    VA_ENTER();
     if (!p)
         return VA_OK;
     (void)hipDeviceSynchronize();
@@ -761,6 +885,7 @@ size_t va_bg_state_bytes(const va_pipeline_t *p) { return p ? p->bg_bytes : 0; }
 
 int va_bg_get_state(va_pipeline_t *p, void *state_host, size_t bytes, int64_t *n_seen)
 {
+    VA_ENTER();
     VA_REQUIRE(p, "va_bg_get_state: NULL pipeline");
     if (n_seen)
         *n_seen = p->n_seen;
@@ -777,6 +902,7 @@ int va_bg_get_state(va_pipeline_t *p, void *state_host, size_t bytes, int64_t *n
 
 int va_bg_set_state(va_pipeline_t *p, const void *state_host, size_t bytes, int64_t n_seen)
 {
+    VA_ENTER();
     VA_REQUIRE(p, "va_bg_set_state: NULL pipeline");
     VA_REQUIRE(n_seen >= 0, "va_bg_set_state: n_seen must be >= 0");
     if (state_host) {
@@ -798,6 +924,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
                     uint8_t *mask_out, int32_t *labels_out, int32_t *counts_out,
                     int64_t *stats_out, void *stream)
 {
+    VA_ENTER();
     VA_REQUIRE(p && frames, "va_pipeline_run: NULL argument");
     const va_config &c = p->cfg;
     VA_REQUIRE(n >= 0 && n <= c.max_batch, "va_pipeline_run: n=%d exceeds max_batch=%d", n,
@@ -887,19 +1014,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     const bool want_ccl = c.connectivity && (labels_out || counts_out || stats_out);
     int32_t *labels = nullptr;
     if (want_ccl) {
-        labels = labels_out;
-        if (!labels) {
-            if (!p->labels_scratch) {
-                hipError_t e = hipMalloc((void **)&p->labels_scratch,
-                                         (size_t)c.max_batch * p->frame_px * sizeof(int32_t));
-                if (e != hipSuccess) {
-                    set_error("va_pipeline_run: hipMalloc(labels scratch) failed: %s",
-                              hipGetErrorString(e));
-                    return VA_ERR_NOMEM;
-                }
-            }
-            labels = p->labels_scratch;
-        }
+        labels = labels_out ? labels_out : p->labels_scratch;
     }
     if (c.morph_count > 0 && morph_fused_supported(c.width, p->se, c.morph_count)) {
         rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], n, c.height, c.width, c.morph_op, p->se,
@@ -926,9 +1041,12 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     }
     // 5. labelling (+ statistics)
     if (want_ccl) {
+        // counts alone come out of the labelling kernels; the label image (the chain's largest
+        // write) is painted only for callers that read it or the per-label statistics
+        const bool paint = labels_out != nullptr || stats_out != nullptr;
         rc = launch_ccl(p->bits[b], labels, counts_out ? counts_out : p->counts_scratch, n,
                         c.height, c.width, c.connectivity, p->ccl_ws, p->ccl_ws_bytes, stats_out,
-                        c.max_labels, st, prof);
+                        c.max_labels, st, prof, paint);
         if (rc)
             return rc;
     }
@@ -938,6 +1056,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
 
 int va_pipeline_profile(va_pipeline_t *p, int enable)
 {
+    VA_ENTER();
     VA_REQUIRE(p, "va_pipeline_profile: NULL pipeline");
     if (!p->prof) {
         p->prof = new (std::nothrow) StageProfiler();
@@ -955,6 +1074,7 @@ int va_pipeline_profile(va_pipeline_t *p, int enable)
 int va_pipeline_stage_times(va_pipeline_t *p, int capacity, char *names, double *total_ms,
                             int32_t *launches, int *nstages_out)
 {
+    VA_ENTER();
     VA_REQUIRE(p && names && total_ms && launches && nstages_out && capacity > 0,
                "va_pipeline_stage_times: bad argument");
     *nstages_out = 0;
@@ -1043,6 +1163,7 @@ static int nccl_load()
 
 int va_comm_unique_id(uint8_t id_out[128])
 {
+    VA_ENTER();
     VA_REQUIRE(id_out, "va_comm_unique_id: NULL argument");
     int rc = nccl_load();
     if (rc)
@@ -1055,6 +1176,7 @@ int va_comm_unique_id(uint8_t id_out[128])
 
 int va_comm_init(void **comm_out, int world_size, int rank, const uint8_t id[128])
 {
+    VA_ENTER();
     VA_REQUIRE(comm_out && id, "va_comm_init: NULL argument");
     VA_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "va_comm_init: bad rank %d/%d",
                rank, world_size);
@@ -1070,6 +1192,7 @@ int va_comm_init(void **comm_out, int world_size, int rank, const uint8_t id[128
 int va_gather_counts(void *comm, const int32_t *send, int32_t *recv, int count_per_rank,
                      void *stream)
 {
+    VA_ENTER();
     VA_REQUIRE(comm && send && recv && count_per_rank >= 0, "va_gather_counts: bad argument");
     int rc = nccl_load();
     if (rc)
@@ -1081,6 +1204,7 @@ int va_gather_counts(void *comm, const int32_t *send, int32_t *recv, int count_p
 
 int va_comm_destroy(void *comm)
 {
+    VA_ENTER();
     if (!comm)
         return VA_OK;
     int rc = nccl_load();

@@ -1456,7 +1456,9 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     VA_REQUIRE(connectivity == 4 || connectivity == 8, "label: connectivity must be 4 or 8 (got %d)",
                connectivity);
     VA_REQUIRE(bits && labels && workspace, "label: NULL argument");
-    VA_REQUIRE((size_t)h * (size_t)w < ((size_t)1 << 31), "label: frame too large for int32 labels");
+    VA_REQUIRE((size_t)h * (size_t)w < kMaxFramePixels,
+               "label: frames of %dx%d exceed the supported 2^29 pixels (32-bit buffer descriptors "
+               "address h*w*4 bytes of labels)", w, h);
     if (n == 0 || h == 0 || w == 0)
         return VA_OK;
     const int w32 = words_per_row(w);

@@ -43,6 +43,9 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
     } while (0)
 
 constexpr int kWave = 64;  // CDNA wavefront width
+// largest frame the kernels take: per-frame byte offsets (4-byte labels) travel in the 32-bit
+// fields of raw buffer descriptors / uint32 arithmetic, so h*w*4 must stay below 2^31
+constexpr size_t kMaxFramePixels = (size_t)1 << 29;
 
 // Optional per-stage timing with HIP events on the pipeline's own stream (bench.py's roofline
 // numbers come from here).  Events are only recorded, never waited for, inside a run.
@@ -184,6 +187,9 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
 int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, int h, int w,
                            unsigned long long *best_keys, int32_t *points, int max_points,
                            int32_t *npoints, double *area, hipStream_t st);
+// cv2.moments(contour): ten spatial moments (float64) per contour, points int32 or float32 (x, y)
+int launch_contour_moments(const void *points, const int32_t *npoints, int n, int max_points,
+                           int is_float, double *out, hipStream_t st);
 int launch_stats_from_labels(const int32_t *labels, int n, int h, int w, int max_labels,
                              int64_t *stats, hipStream_t st);
 int launch_largest_region(const int32_t *labels, const int32_t *counts, const int64_t *stats,

@@ -153,7 +153,7 @@ int launch_thinning_step(const uint8_t *img, uint8_t *eroded, uint8_t *skel, int
     size_t total = (size_t)n * h * w;
     if (total == 0)
         return VA_OK;
-    VA_HIP(hipMemsetAsync(nonzero, 0, sizeof(unsigned long long), st));
+    // `nonzero` is this iteration's own counter; the caller zeroes the counter array once
     thinning_step_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(img, eroded, skel, h, w,
                                                                            total, nonzero);
     VA_LAUNCH_CHECK("thinning_step_kernel");

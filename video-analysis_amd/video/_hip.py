@@ -98,6 +98,7 @@ SIGNATURES = {
     "va_image_statistics_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp]),
     "va_contour_workspace_bytes": (_sz, [_i, _i, _i]),
     "va_largest_contour": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "va_contour_moments": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "va_pipeline_create": (_i, [C.POINTER(va_config), C.POINTER(_vp)]),
     "va_pipeline_destroy": (_i, [_vp]),
     "va_pipeline_run": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -147,19 +148,31 @@ def check(code):
 
 
 def lib(device=None):
-    """library handle with an initialised GPU; raises HipUnavailableError without one"""
+    """library handle with an initialised GPU; raises HipUnavailableError without one.
+
+    One device per process (one process per GPU, as bench.py / torch.distributed launch them): the
+    first call selects `device` (default: $VA_DEVICE, else $LOCAL_RANK, else 0); asking for a
+    device that is not visible, or for a second device later, raises instead of silently running
+    somewhere else."""
     global _ready_device
     L = load_library()
-    if _ready_device is None or (device is not None and device != _ready_device):
+    if _ready_device is None:
         if device is None:
             device = int(os.environ.get("VA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        if L.va_device_count() <= 0:
+        count = L.va_device_count()
+        if count <= 0:
             raise HipUnavailableError("no HIP device visible: the video filters/analysis ops "
                                       "run on MI355X only (no CPU fallback)")
-        if device >= L.va_device_count():
-            device = 0
+        if not 0 <= device < count:
+            raise HipUnavailableError("device %d requested but only %d GPU(s) are visible to this "
+                                      "process (check LOCAL_RANK / VA_DEVICE / HIP_VISIBLE_DEVICES)"
+                                      % (device, count))
         check(L.va_init(device))
         _ready_device = device
+    elif device is not None and device != _ready_device:
+        raise ValueError("this process already runs on GPU %d; device %d requested (the library "
+                         "uses one device per process: start one process per GPU)"
+                         % (_ready_device, device))
     return L
 
 

@@ -57,8 +57,16 @@ def image_moments(mask):
     return moments_from_spatial(ops.region_stats(m, 1)[0][:10])
 
 
+def contour_moments(contour):
+    """cv2.moments(contour) (image.py:355; shapes.py:533): Green's-theorem moments of a closed
+    polygon given as (N, 2) / (N, 1, 2) points.  Integer arrays are read as int32 points, all
+    other dtypes as float32 points, like Polygon.moments' explicit cast in the reference."""
+    from .. import ops
+    return moments_from_spatial(ops.contour_moments(contour))
+
+
 class regionprops(object):
-    """properties of a region given by a boolean mask or by precomputed moments
+    """properties of a region given by a boolean mask, by its contour or by precomputed moments
     (reference :310-405; the formulas follow scikit-image, as the reference notes)"""
 
     def __init__(self, mask=None, contour=None, moments=None):
@@ -67,7 +75,7 @@ class regionprops(object):
         elif mask is not None:
             self.moments = image_moments(mask)
         elif contour is not None:
-            raise NotImplementedError("contour moments are outside the GPU hot path")
+            self.moments = contour_moments(contour)
         else:
             raise ValueError("Either the mask or the moments must be given")
 

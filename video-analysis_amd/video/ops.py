@@ -277,9 +277,11 @@ def largest_region(mask, connectivity=4):
             b.free()
 
 
-def largest_contour(mask, max_points=None):
+def largest_contour(mask, max_points=None, moments=False):
     """outer contour (cv2 RETR_EXTERNAL / CHAIN_APPROX_SIMPLE) of the component with the largest
-    contour area.  returns (points (N,2) int32, area float, number of components)"""
+    contour area.  returns (points (N,2) int32, area float, number of components); with
+    moments=True also the ten spatial cv2.moments(contour) values, computed from the points while
+    they are still on the device"""
     m = np.asarray(mask)
     if m.ndim != 2:
         raise ValueError("mask must be 2-d")
@@ -306,10 +308,36 @@ def largest_contour(mask, max_points=None):
             cap = n                       # rare: a very long contour, run again with room for it
         count = int(ncomp.download((1,), np.int32)[0])
         points = pts.download((min(n, cap), 2), np.int32)
-        return points, float(area.download((1,), np.float64)[0]), count
+        res = (points, float(area.download((1,), np.float64)[0]), count)
+        if moments:
+            mom = DeviceBuffer(10 * 8)
+            bufs.append(mom)
+            check(L.va_contour_moments(pts.ptr, npts.ptr, 1, cap, 0, mom.ptr, None))
+            res += (mom.download((10,), np.float64),)
+        return res
     finally:
         for b in bufs:
             b.free()
+
+
+def contour_moments(contour):
+    """the ten spatial moments of cv2.moments(contour) as a float64 array (m00 m10 m01 m20 m11 m02
+    m30 m21 m12 m03) -- regionprops(contour=...), video/analysis/image.py:355; Polygon.moments,
+    video/analysis/shapes.py:533.  Integer arrays are int32 points, everything else float32
+    points (the two forms cv2.moments accepts; other dtypes it would read as an image)."""
+    c = np.asarray(contour)
+    if c.size == 0 or c.size % 2:
+        raise ValueError("contour must hold (x, y) points")
+    is_float = 0 if np.issubdtype(c.dtype, np.integer) else 1
+    c = np.ascontiguousarray(c.reshape(-1, 2), np.float32 if is_float else np.int32)
+    pts = DeviceBuffer.from_array(c)
+    out = DeviceBuffer(10 * 8)
+    try:
+        check(_hip.lib().va_contour_moments(pts.ptr, None, 1, len(c), is_float, out.ptr, None))
+        return out.download((10,), np.float64)
+    finally:
+        pts.free()
+        out.free()
 
 
 def detect_peaks(img, include_plateaus=True):
