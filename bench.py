@@ -154,20 +154,21 @@ def cpu_baseline_main(argv):
     import multiprocessing as mp
     import numpy as np
     from oracle import oracle as O
-    path, sigma, thresh, morph = argv[0], float(argv[1]), int(argv[2]), int(argv[3])
+    path, sigma, thresh, morph, n1 = argv[0], float(argv[1]), int(argv[2]), int(argv[3]), int(argv[4])
     O.build()
     frames = np.load(path)
     n, h, w = frames.shape
+    n1 = max(1, min(n1, n))
     cores = _cpu_count()
-    # -- 1 thread
+    # -- 1 thread, the first n1 frames
     t0 = time.perf_counter()
-    mask, labels, counts, _ = O.chain_u8(frames, sigma, thresh, morph_ksize=morph, connectivity=4,
+    mask, labels, counts, _ = O.chain_u8(frames[:n1], sigma, thresh, morph_ksize=morph, connectivity=4,
                                          want_mask=True, want_labels=True)
     dt1 = time.perf_counter() - t0
-    res = {"value": round(n / dt1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+    res = {"value": round(n1 / dt1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "%d of the batch's %dx%d frames, full chain incl. labelling, oracle/va_oracle.c "
                      "gcc -O3 -march=native, 1 thread of %d usable host cores (os.cpu_count()=%d), %.1f s"
-                     % (n, w, h, cores, os.cpu_count() or 0, dt1)}
+                     % (n1, w, h, cores, os.cpu_count() or 0, dt1)}
     # -- all cores
     workers = max(1, min(cores, 64))
     diff_path = path + ".diff.npy"
@@ -183,16 +184,16 @@ def cpu_baseline_main(argv):
                   for k in range(workers) if n * k // workers < n * (k + 1) // workers]
         par_counts = [c for part in pool.map(_cpu_chain_frames, shards) for c in part]
         dtp = time.perf_counter() - t0
-    if list(par_counts) != [int(c) for c in counts]:
+    if list(par_counts)[:n1] != [int(c) for c in counts]:
         raise SystemExit("cpu baseline: sharded chain disagrees with the sequential one")
     res["all_cores"] = {"value": round(n / dtp, 3), "unit": "frames/s", "cores": workers,
-                        "sample": "same %d frames: background pass sharded over image rows, then frames "
-                                  "sharded over %d forked processes, %.1f s" % (n, workers, dtp)}
+                        "sample": "the whole batch of %d frames: background pass sharded over image rows, then "
+                                  "frames sharded over %d forked processes, %.1f s" % (n, workers, dtp)}
     os.unlink(diff_path)
     # -- the literal reference recipe, where it exists without cv2
     try:
         from scipy import ndimage
-        k = min(4, n)
+        k = min(4, n1)
         t0 = time.perf_counter()
         mean = np.zeros((h, w), np.double)
         for i in range(k):                                      # video/analysis/video.py:30-33
@@ -201,7 +202,7 @@ def cpu_baseline_main(argv):
         t0 = time.perf_counter()
         nlab = 0
         for i in range(k):                                      # video/analysis/regions.py:162-169
-            lab, num = ndimage.label(mask[n - 1 - i])
+            lab, num = ndimage.label(mask[n1 - 1 - i])
             areas = [np.sum(lab == l) for l in range(1, num + 1)]
             nlab += num
             if areas:
@@ -504,8 +505,7 @@ def main():
                       "stage_avg_ms": stage_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(frames[:max(args.cpu_frames, 1)].cpu().numpy(),
-                                               (sigma, thresh, morph))
+            res["cpu_baseline"] = cpu_baseline(frames.cpu().numpy(), (sigma, thresh, morph, max(args.cpu_frames, 1)))
         print(json.dumps(res), flush=True)
     if distributed:
         dist.barrier()

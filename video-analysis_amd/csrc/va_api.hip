@@ -100,6 +100,7 @@ struct va_pipeline {
     RowSpans se[VA_MAX_MORPH_OPS];
     bool fused;   // single-launch blur(+threshold+bits): MFMA or LDS/VALU kernel
     bool mfma;
+    bool f32_fused;   // float32: [EMA + row pass] and marching column pass (va_gauss_f32_fused.hip)
     char desc[160];
     StageProfiler *prof;
 };
@@ -424,6 +425,9 @@ int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, do
     rc = scratch.acquire((size_t)n * h * w * c * sizeof(float), as_stream(stream));
     if (rc)
         return rc;
+    if (gauss_f32_fused_supported(h, w, c, t) && reinterpret_cast<uintptr_t>(src) % 16 == 0)
+        return launch_gauss_f32_fused(src, dst, (float *)scratch.ptr, nullptr, 0, 0.0, n, h, w, c, t,
+                                      as_stream(stream));
     if (gauss_f32_fast_supported(w, c, t))
         return launch_gauss_f32_fast(src, dst, (float *)scratch.ptr, n, h, w, c, t, as_stream(stream));
     return launch_gauss_generic_f32(src, dst, (float *)scratch.ptr, n, h, w, c, t, as_stream(stream));
@@ -807,6 +811,7 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
                        (cfg->channels == 1 && gauss_fused_supported(cfg->width, cfg->height, p->tq));
         } else {
             PIPE_TRY(gauss_taps_f32(cfg->sigma, &p->tf.ksize, p->tf.t, kMaxTaps));
+            p->f32_fused = gauss_f32_fused_supported(cfg->height, cfg->width, cfg->channels, p->tf);
         }
     }
     for (int i = 0; i < cfg->morph_count; i++) {
@@ -826,7 +831,8 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
             pipeline_free(p);
             return VA_ERR_HIP;
         }
-        PIPE_MALLOC(p->diff, nb * p->px * esz);
+        if (!p->f32_fused)      // (the fused float path never materialises the difference image)
+            PIPE_MALLOC(p->diff, nb * p->px * esz);
         if (cfg->bg_mode == VA_BG_MEAN)
             PIPE_MALLOC(p->bg_recip, bg_scratch_bytes(cfg->max_batch));
     }
@@ -857,7 +863,9 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
     snprintf(p->desc, sizeof(p->desc), "bg=%d gauss=%s(ksize=%d) thresh=%d morph=%d ccl=%d",
              cfg->bg_mode,
              cfg->sigma > 0 ? (p->fused ? (p->mfma ? "mfma-i8" : "fused-lds")
-                                        : (cfg->dtype == VA_F32 &&
+                                        : (cfg->dtype == VA_F32 && p->f32_fused
+                                               ? "f32-ema-row+col-march"
+                                               : cfg->dtype == VA_F32 &&
                                                    gauss_f32_fast_supported(cfg->width, cfg->channels, p->tf)
                                                ? "f32-packed"
                                                : (p->planes_wp ? "mfma-i8-planes" : "generic")))
@@ -949,6 +957,18 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     } while (0)
     VA_MARK(nullptr);
 
+    // float32 frames: background update, difference and row pass in one kernel, then the columns
+    if (c.dtype == VA_F32 && p->f32_fused) {
+        void *dst = filtered_out ? filtered_out : p->blur;
+        rc = launch_gauss_f32_fused((const float *)frames, (float *)dst, (float *)p->gscratch,
+                                    c.bg_mode == VA_BG_EMA ? (float *)p->bg_state : nullptr, p->n_seen,
+                                    (double)c.bg_rate, n, c.height, c.width, c.channels, p->tf, st, prof);
+        if (rc)
+            return rc;
+        if (c.bg_mode == VA_BG_EMA)
+            p->n_seen += n;
+        return VA_OK;
+    }
     // 1. background subtraction (temporal, in frame order)
     if (c.bg_mode != VA_BG_NONE) {
         rc = launch_bg(c.bg_mode, c.dtype, cur, p->diff, p->bg_state, p->n_seen, (double)c.bg_rate,

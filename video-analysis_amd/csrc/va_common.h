@@ -104,6 +104,12 @@ int launch_gauss_generic_f32(const float *src, float *dst, float *scratch, int n
 bool gauss_f32_fast_supported(int w, int c, const TapsF32 &taps);
 int launch_gauss_f32_fast(const float *src, float *dst, float *scratch, int n, int h, int w, int c,
                           const TapsF32 &taps, hipStream_t st);
+// float32 path in two kernels (va_gauss_f32_fused.hip): [EMA background + |difference| + row pass]
+// with the background state in registers, then a marching column pass.  bg == nullptr: plain blur.
+bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps);
+int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *bg, int64_t n_seen,
+                           double rate, int n, int h, int w, int c, const TapsF32 &taps, hipStream_t st,
+                           StageProfiler *prof = nullptr);
 // fused single-channel u8 Gaussian (LDS-staged, dot4/dot2), radius <= 31; output either the
 // blurred u8 frames (dst), and/or the thresholded bit mask (bits, blurred > thresh)
 bool gauss_fused_supported(int w, int h, const TapsQ8 &taps);

@@ -1,0 +1,804 @@
+// va_gauss_f32_fused.hip -- float32 path of BASELINE.json configs[4] in two kernels:
+//
+//   1. ema_row_f32_kernel   adaptive background (EMA) + |frame - bg| + Gaussian ROW pass
+//   2. col_march_f32_kernel Gaussian COLUMN pass, marching down the frame
+//
+// replaces  FilterBackground(mode='ema') (BUILD-DEFINED, arithmetic of oracle vao_bg_ema_f32)
+//           followed by cv2.GaussianBlur(float image, (0, 0), sigma),
+//           video/analysis/active_contour.py:108
+//
+// Why two kernels and not three (EMA, rows, columns) or one: the EMA is a recurrence over time,
+// the blur a stencil over space.  sigma = 9 means 146 FMA-class operations per sample against
+// 8 compulsory bytes, so each pass is worth about as much VALU time (1.7 ms per 256 x 1080p x 3
+// at the packed-fp32 rate) as its HBM time (2.1 ms); three kernels move 38 GB for 12.7 GB of
+// compulsory traffic.  Fusing everything would need every workgroup to own a 2-d tile plus a
+// 36-pixel halo on all sides for all frames (3x redundant work at 256 CUs).  So:
+//
+//   * kernel 1 keeps the background state in REGISTERS: a workgroup owns one contiguous chunk of
+//     the flattened frame (about total/1024 samples, i.e. every CU gets the same work; the chunk
+//     may straddle row ends) for ALL frames of the batch, reads each frame's chunk once, updates
+//     its state, stages |frame - bg| (with the row halos; reflected at row ends) in LDS as float2
+//     pairs (first half of the chunk, second half), runs the row pass with v_pk_fma_f32 (both
+//     halves use the same tap, so every packed operand is register-aligned), and writes the
+//     row-filtered samples back as 16-byte pieces.  The difference image never exists in HBM.
+//   * kernel 2 gives a workgroup a 64-sample column strip of one frame and marches down 64 rows
+//     at a time, keeping the last 2r rows in LDS, so the intermediate image is read exactly once
+//     (the tile-per-workgroup version read it 2.1 times).
+//
+// Arithmetic order is the oracle's (vao_bg_ema_f32 / vao_gaussian_f32): no contraction in the
+// EMA (built with -ffp-contract=off), in-order fmaf chain over the taps in the row pass, centre
+// tap then symmetric pairs in the column pass -- results are bit-identical.
+#include "va_common.h"
+
+namespace va {
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1)
+        return 0;
+    while (p < 0 || p >= len)
+        p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+constexpr int kT = 256;        // threads per workgroup (4 waves, one per SIMD; 4 workgroups per CU)
+constexpr int kP = 15;         // outputs per thread and half (multiple of the channel count)
+constexpr int kNV = 7;         // float4 loads per thread and frame
+constexpr int kMaxSeg = 4;     // row pieces a chunk may consist of
+constexpr int kHalfCap = kP * kT;   // window positions per half
+
+struct RowPlan {
+    int L;        // samples per chunk (multiple of 4)
+    int nchunks;
+};
+
+// a chunk of L flat samples touches at most this many rows
+inline int max_segments(long long L, int rw) { return (int)((L + rw - 2) / rw) + 1; }
+
+// Row pieces of one sub-chunk [cs, ce) of the flattened frame and where they sit in the padded
+// array X = [halo | piece 0 | halo][halo | piece 1 | halo]...  (all uniform: SGPRs)
+struct ChunkTab {
+    int cs, ce;            // flat sample range owned
+    int FS, FE;            // flat range loaded (with the halos of the first / last piece), float4 units
+    int XL, Hoff;          // length of X, start of its second half
+    int rs[kMaxSeg];       // flat index of the row start of piece k
+    int qa[kMaxSeg], qb[kMaxSeg];   // in-row sample range of piece k (qa == qb: unused)
+    int xoff[kMaxSeg];     // start of piece k's padded block in X
+    int delta[kMaxSeg];    // a loaded flat sample f of piece k sits at X index f + delta[k] ...
+    int blo[kMaxSeg], bhi[kMaxSeg];   // ... provided that index lies in [blo[k], bhi[k])
+    int pofs[kMaxSeg];     // the output for flat sample f is O[f + pofs[k]]
+};
+
+__device__ __forceinline__ ChunkTab make_tab(int cs_in, int L, int total, int h, int rw, int halo)
+{
+    ChunkTab T;
+    T.cs = min(cs_in, total);
+    T.ce = min(T.cs + L, total);
+    const int yfirst = T.cs / rw;
+    T.XL = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxSeg; k++) {
+        T.rs[k] = min(yfirst + k, h) * rw;           // (rows past the frame: empty pieces)
+        const int a = max(T.cs, T.rs[k]), b = min(T.ce, min(T.rs[k] + rw, total));
+        T.qa[k] = a < b ? a - T.rs[k] : 0;
+        T.qb[k] = a < b ? b - T.rs[k] : 0;
+        T.xoff[k] = T.XL;
+        if (a < b)
+            T.XL += (T.qb[k] - T.qa[k]) + 2 * halo;
+    }
+    T.Hoff = (T.XL + 1) >> 1;
+    T.FS = T.cs;
+    T.FE = T.ce;
+#pragma unroll
+    for (int k = 0; k < kMaxSeg; k++) {
+        if (T.qa[k] < T.qb[k]) {
+            T.FS = min(T.FS, T.rs[k] + max(0, ((T.qa[k] - halo) >> 2) << 2));
+            T.FE = max(T.FE, T.rs[k] + min(rw, ((T.qb[k] + halo + 3) >> 2) << 2));
+        }
+        T.delta[k] = T.xoff[k] + halo - T.rs[k] - T.qa[k];
+        T.pofs[k] = T.xoff[k] - T.rs[k] - T.qa[k];
+        T.blo[k] = T.xoff[k];
+        T.bhi[k] = T.qa[k] < T.qb[k] ? T.xoff[k] + (T.qb[k] - T.qa[k]) + 2 * halo : T.xoff[k];
+    }
+    return T;
+}
+
+// Workgroup = 8 waves with two roles (wave-uniform): waves 0-3 LOAD (they own the background
+// state, read the frames, stage |frame - bg| into LDS and write the results out), waves 4-7
+// COMPUTE (the row pass).  A workgroup owns two sub-chunks; while the compute waves filter one
+// of them from its LDS buffer, the loader waves stage the other one into the second buffer and
+// already have the loads after that in flight, so HBM traffic and VALU work overlap inside every
+// workgroup instead of depending on the phase of its neighbours (measured before the split: all
+// workgroups of a CU ran their memory phases together and then their VALU phases together --
+// 2.9 ms + 2.4 ms).  Two workgroups per CU: 2 compute + 2 loader waves per SIMD.
+template <int C, bool EMA>
+__global__ void __launch_bounds__(2 * kT, 4)
+ema_row_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, float *__restrict__ bg,
+                   long long n_seen, float rate, int nframes, int h, int w, int L, TapsF32 taps)
+{
+    extern __shared__ f2 lds[];    // [buffer 0][buffer 1][staging map]
+    constexpr int WIN = kP + C;
+    constexpr int PERIOD = WIN / C;
+    static_assert(WIN % C == 0, "kP must be a multiple of C");
+    const int rw = w * C;
+    const int nt = taps.ksize, r = nt >> 1, halo = r * C;
+    const int total = h * rw;                       // < 2^31: frames of at most 2^29 pixels, C <= 3
+    const size_t fstride = (size_t)total;
+    const int reach = (nt - 1) * C + kP;            // X entries a window start may read ahead
+    const int s2n = kHalfCap + reach + 1;           // entries of one buffer (allocated: s2n + 7)
+    f2 *const buf0 = lds, *const buf1 = lds + (s2n + 7);
+    unsigned short *const sinfo = reinterpret_cast<unsigned short *>(lds + 2 * (s2n + 7));   // [2][kNV][kT]
+    const bool loader = threadIdx.x < kT;           // wave-uniform
+    const int tid = threadIdx.x & (kT - 1);
+
+    const ChunkTab T0 = make_tab((2 * blockIdx.x) * L, L, total, h, rw, halo);
+    const ChunkTab T1 = make_tab((2 * blockIdx.x + 1) * L, L, total, h, rw, halo);
+    const int f0 = EMA ? 0 : blockIdx.y, f1 = EMA ? nframes : blockIdx.y + 1;
+    const int Q = 2 * (f1 - f0);                    // phases: (frame, sub-chunk) in order
+
+    // an X element lives in .x of entry u (u < s2n) and/or in .y of entry u - Hoff (u >= Hoff)
+    auto x_store = [&](float *sf, int Hoff, int u, float v) {
+        if (u < s2n)
+            sf[2 * u] = v;
+        if (u >= Hoff)
+            sf[2 * (u - Hoff) + 1] = v;
+    };
+    auto x_load = [&](const float *sf, int Hoff, int u) -> float {
+        return u < s2n ? sf[2 * u] : sf[2 * (u - Hoff) + 1];
+    };
+
+    // ======================================================================= loader waves
+    if (loader) {
+        // staging map, computed once and parked in LDS (16 bits per load slot): for slot m of this
+        // thread (the float4 at flat index FS + 4*(tid + kT*m); its four samples lie in one row
+        // because rw % 4 == 0) the X index of its first sample and a class: 0 nothing to stage,
+        // 1 all four samples go to the first half only, 2 to the second half only, 3 anything else
+        auto make_map = [&](const ChunkTab &T, int sub) {
+#pragma unroll
+            for (int m = 0; m < kNV; m++) {
+                const int fm = T.FS + 4 * tid + 4 * kT * m;
+                int info = 0;
+                if (fm < T.FE) {
+                    int dk = T.delta[0], lo = T.blo[0], hi = T.bhi[0];
+#pragma unroll
+                    for (int k = 1; k < kMaxSeg; k++)
+                        if (fm >= T.rs[k] && T.qa[k] < T.qb[k]) {
+                            dk = T.delta[k];
+                            lo = T.blo[k];
+                            hi = T.bhi[k];
+                        }
+                    const int u0 = fm + dk;
+                    int nvalid = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        nvalid += (u0 + e >= lo && u0 + e < hi) ? 1 : 0;
+                    const int cls = nvalid == 0 ? 0
+                                    : (nvalid == 4 && u0 + 3 < T.Hoff) ? 1
+                                    : (nvalid == 4 && u0 >= s2n)      ? 2
+                                                                      : 3;
+                    info = ((u0 + 8) << 2) | cls;
+                }
+                sinfo[(sub * kNV + m) * kT + tid] = (unsigned short)info;
+            }
+        };
+        make_map(T0, 0);
+        make_map(T1, 1);
+        float st0[kNV][4], st1[kNV][4];             // background state of both sub-chunks (+ halos)
+        auto load_state = [&](const ChunkTab &T, float (&st)[kNV][4]) {
+#pragma unroll
+            for (int m = 0; m < kNV; m++) {
+                const int fm = T.FS + 4 * tid + 4 * kT * m;
+                f4 v = f4{0.f, 0.f, 0.f, 0.f};
+                if (EMA && fm < T.FE)
+                    v = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(bg) + (unsigned)(4 * fm));
+                st[m][0] = v.x, st[m][1] = v.y, st[m][2] = v.z, st[m][3] = v.w;
+            }
+        };
+        load_state(T0, st0);
+        load_state(T1, st1);
+        const f2 rate2 = f2{rate, rate};
+        f4 ldA[kNV];
+        auto issue_loads = [&](const ChunkTab &T, int f, f4 (&ld)[kNV]) {
+            const char *fr = reinterpret_cast<const char *>(frames + (size_t)f * fstride);   // uniform base + 32-bit lane byte offset
+            int fb = T.FS + 4 * tid;
+            asm volatile("" : "+v"(fb));            // (keeps seven load addresses out of loop-invariant registers)
+#pragma unroll
+            for (int m = 0; m < kNV; m++)
+                if (fb + 4 * kT * m < T.FE)
+                    ld[m] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(fr + (unsigned)(4 * (fb + 4 * kT * m))));
+        };
+        // background update + |difference| of the loaded sub-chunk into buffer `buf`
+        auto stage = [&](const ChunkTab &T, int sub, f2 *buf, float (&st)[kNV][4], bool first, const f4 (&ld)[kNV]) {
+            float *sf = reinterpret_cast<float *>(buf);
+            int sbase = sub * kNV * kT + tid;
+            asm volatile("" : "+v"(sbase));
+#pragma unroll
+            for (int m = 0; m < kNV; m++) {
+                const int info = sinfo[sbase + m * kT];
+                const int cls = info & 3, u0 = (info >> 2) - 8;
+                if (cls != 0) {
+                    f2 va = f2{ld[m].x, ld[m].y}, vb = f2{ld[m].z, ld[m].w};
+                    if (EMA) {
+                        f2 sa = f2{st[m][0], st[m][1]}, sb = f2{st[m][2], st[m][3]};
+                        if (first) {
+                            sa = va;
+                            sb = vb;
+                        }
+                        const f2 da = va - sa, db = vb - sb;            // oracle order: d = x - bg
+                        const f2 ta = rate2 * da, tb = rate2 * db;      // step = rate * d   (no contraction)
+                        sa = sa + ta;                                   // bg = bg + step
+                        sb = sb + tb;
+                        va = __builtin_elementwise_abs(da);
+                        vb = __builtin_elementwise_abs(db);
+                        st[m][0] = sa.x, st[m][1] = sa.y, st[m][2] = sb.x, st[m][3] = sb.y;
+                    }
+                    const float v[4] = {va.x, va.y, vb.x, vb.y};
+                    if (cls == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            sf[2 * (u0 + e)] = v[e];
+                    } else if (cls == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            sf[2 * (u0 + e - T.Hoff) + 1] = v[e];
+                    } else {
+                        // block edges / the band both halves read: bounds of this sample's piece
+                        const int fm = T.FS + 4 * tid + 4 * kT * m;
+                        int lo = T.blo[0], hi = T.bhi[0];
+#pragma unroll
+                        for (int k = 1; k < kMaxSeg; k++)
+                            if (fm >= T.rs[k] && T.qa[k] < T.qb[k]) {
+                                lo = T.blo[k];
+                                hi = T.bhi[k];
+                            }
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (u0 + e >= lo && u0 + e < hi)
+                                x_store(sf, T.Hoff, u0 + e, v[e]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // halos beyond a row end: BORDER_REFLECT_101, copied inside LDS
+        auto fixup = [&](const ChunkTab &T, f2 *buf) {
+            float *sf = reinterpret_cast<float *>(buf);
+#pragma unroll
+            for (int k = 0; k < kMaxSeg; k++) {
+                if (T.qa[k] >= T.qb[k] || (T.qa[k] >= halo && T.qb[k] + halo <= rw))   // uniform: nothing past a row end
+                    continue;
+                for (int j = tid; j < halo; j += kT) {
+                    const int ql = T.qa[k] - halo + j;                  // left halo slot j
+                    if (ql < 0) {                                       // before the row start
+                        const int px = -((-ql + C - 1) / C), ch = ql - px * C;
+                        const int qs = reflect101(px, w) * C + ch;
+                        x_store(sf, T.Hoff, T.xoff[k] + j, x_load(sf, T.Hoff, T.xoff[k] + halo + (qs - T.qa[k])));
+                    }
+                    const int qr = T.qb[k] + j;                         // right halo slot j
+                    if (qr >= rw) {                                     // past the row end
+                        const int px = qr / C, ch = qr - px * C;
+                        const int qs = reflect101(px, w) * C + ch;
+                        x_store(sf, T.Hoff, T.xoff[k] + halo + (T.qb[k] - T.qa[k]) + j,
+                                x_load(sf, T.Hoff, T.xoff[k] + halo + (qs - T.qa[k])));
+                    }
+                }
+            }
+        };
+        // results of phase q leave as 16-byte pieces (the loaders' share: slots 2m)
+        auto copy_out = [&](const ChunkTab &T, const f2 *buf, int f, int part) {
+            const float *O = reinterpret_cast<const float *>(buf);
+            char *out = reinterpret_cast<char *>(tmp + (size_t)f * fstride);
+            int ocs = T.cs + 4 * tid;
+            asm volatile("" : "+v"(ocs));
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                // the 1024 samples of output slot (2m + part) lie in at most two pieces
+                const int sa = T.cs + 4 * kT * (2 * m + part), sb = min(sa + 4 * kT, T.ce) - 1;
+                if (sa >= T.ce)                      // uniform
+                    break;
+                int pa = T.pofs[0], pb = T.pofs[0], rsb = 0, ka = 0, kb = 0;
+#pragma unroll
+                for (int k = 1; k < kMaxSeg; k++)
+                    if (T.qa[k] < T.qb[k]) {
+                        if (sa >= T.rs[k]) {
+                            pa = T.pofs[k];
+                            ka = k;
+                        }
+                        if (sb >= T.rs[k]) {
+                            pb = T.pofs[k];
+                            rsb = T.rs[k];
+                            kb = k;
+                        }
+                    }
+                const int fo = ocs + 4 * kT * (2 * m + part);
+                if (fo < T.ce) {
+                    int p = fo + (fo >= rsb ? pb : pa);
+                    if (kb - ka > 1) {               // uniform: rows shorter than a slot, three pieces
+                        p = fo + T.pofs[0];
+#pragma unroll
+                        for (int k = 1; k < kMaxSeg; k++)
+                            if (T.qa[k] < T.qb[k] && fo >= T.rs[k])
+                                p = fo + T.pofs[k];
+                    }
+                    const f4 v = f4{O[p], O[p + 1], O[p + 2], O[p + 3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (unsigned)(4 * fo)));
+                }
+            }
+        };
+
+        // The loader waves' few instructions must not queue behind the compute waves' dense
+        // v_pk_fma stream on the shared SIMDs (measured: 8-12k cycles for ~300 instructions).
+        __builtin_amdgcn_s_setprio(3);
+        // prologue: phase 0's data staged, phase 1's loads in flight
+        issue_loads(T0, f0, ldA);
+        stage(T0, 0, buf0, st0, EMA && (n_seen + f0) == 0, ldA);
+        issue_loads(T1, f0, ldA);
+        __syncthreads();
+        fixup(T0, buf0);
+        __syncthreads();
+        for (int q = 0; q < Q; q += 2) {
+            const int f = f0 + (q >> 1);
+            // ---- phase q: the compute waves filter buffer 0 (sub-chunk 0 of frame f) ----------
+            // (one register set for the loads: a second one, so that the next loads could be issued
+            // before this staging, spills the background state -- measured slower)
+            stage(T1, 1, buf1, st1, EMA && (n_seen + f) == 0, ldA);     // sub-chunk 1 of frame f
+            if (f + 1 < f1)
+                issue_loads(T0, f + 1, ldA);
+            __syncthreads();                                            // A: row pass done, staging done
+            fixup(T1, buf1);
+            __syncthreads();                                            // B: O written
+            copy_out(T0, buf0, f, 0);
+            __syncthreads();                                            // C: buffer 0 free
+            // ---- phase q + 1: buffer 1 (sub-chunk 1 of frame f) ----------------------------------
+            if (f + 1 < f1) {
+                stage(T0, 0, buf0, st0, false, ldA);                    // sub-chunk 0 of frame f + 1
+                issue_loads(T1, f + 1, ldA);
+            }
+            __syncthreads();
+            if (f + 1 < f1)
+                fixup(T0, buf0);
+            __syncthreads();
+            copy_out(T1, buf1, f, 0);
+            __syncthreads();
+        }
+        if (EMA) {
+            auto save_state = [&](const ChunkTab &T, float (&st)[kNV][4]) {
+#pragma unroll
+                for (int m = 0; m < kNV; m++) {
+                    const int fm = T.FS + 4 * tid + 4 * kT * m;
+                    if (fm >= T.cs && fm < T.ce)                      // only the sub-chunk's own samples
+                        *reinterpret_cast<f4 *>(reinterpret_cast<char *>(bg) + (unsigned)(4 * fm)) =
+                            f4{st[m][0], st[m][1], st[m][2], st[m][3]};
+                }
+            };
+            save_state(T0, st0);
+            save_state(T1, st1);
+        }
+        return;
+    }
+
+    // ====================================================================== compute waves
+    const int i0 = kP * tid;
+    // row pass: in-order fmaf chain over the taps, two halves per lane; results into O[] (the
+    // same buffer: window start p <-> output X index p + halo) after barrier A
+    auto row_pass = [&](const ChunkTab &T, const f2 *s2, f2 (&acc)[kP]) {
+        if (i0 >= T.Hoff)
+            return;
+        f2 win[WIN];
+#pragma unroll
+        for (int j = 0; j < kP; j++) {
+            acc[j] = f2{0.0f, 0.0f};
+            win[j] = s2[i0 + j];
+        }
+        int k0 = 0;
+        for (; k0 + PERIOD <= nt; k0 += PERIOD) {
+            float wk[PERIOD];
+#pragma unroll
+            for (int t = 0; t < PERIOD; t++)
+                wk[t] = taps.t[k0 + t];
+#pragma unroll
+            for (int t = 0; t < PERIOD; t++) {
+                f2 nx[C];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    nx[c] = s2[i0 + (k0 + t) * C + kP + c];
+                const f2 w2 = f2{wk[t], wk[t]};
+#pragma unroll
+                for (int j = 0; j < kP; j++)
+                    acc[j] = pk_fma(win[(t * C + j) % WIN], w2, acc[j]);
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    win[(t * C + kP + c) % WIN] = nx[c];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PERIOD; t++) {
+            const int k = k0 + t;
+            if (k < nt) {                                // uniform
+                const f2 w2 = f2{taps.t[k], taps.t[k]};
+                f2 nx[C];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    nx[c] = s2[i0 + k * C + kP + c];
+#pragma unroll
+                for (int j = 0; j < kP; j++)
+                    acc[j] = pk_fma(win[(t * C + j) % WIN], w2, acc[j]);
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    win[(t * C + kP + c) % WIN] = nx[c];
+            }
+        }
+    };
+    auto write_O = [&](const ChunkTab &T, f2 *buf, const f2 (&acc)[kP]) {
+        if (i0 >= T.Hoff)
+            return;
+        float *O = reinterpret_cast<float *>(buf);
+#pragma unroll
+        for (int j = 0; j < kP; j++) {
+            O[i0 + j] = acc[j].x;
+            O[T.Hoff + i0 + j] = acc[j].y;
+        }
+    };
+    auto copy_out_c = [&](const ChunkTab &T, const f2 *buf, int f) {   // the compute waves' share: slots 2m + 1
+        const float *O = reinterpret_cast<const float *>(buf);
+        char *out = reinterpret_cast<char *>(tmp + (size_t)f * fstride);
+        int ocs = T.cs + 4 * tid;
+        asm volatile("" : "+v"(ocs));
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int sa = T.cs + 4 * kT * (2 * m + 1), sb = min(sa + 4 * kT, T.ce) - 1;
+            if (sa >= T.ce)                          // uniform
+                break;
+            int pa = T.pofs[0], pb = T.pofs[0], rsb = 0, ka = 0, kb = 0;
+#pragma unroll
+            for (int k = 1; k < kMaxSeg; k++)
+                if (T.qa[k] < T.qb[k]) {
+                    if (sa >= T.rs[k]) {
+                        pa = T.pofs[k];
+                        ka = k;
+                    }
+                    if (sb >= T.rs[k]) {
+                        pb = T.pofs[k];
+                        rsb = T.rs[k];
+                        kb = k;
+                    }
+                }
+            const int fo = ocs + 4 * kT * (2 * m + 1);
+            if (fo < T.ce) {
+                int p = fo + (fo >= rsb ? pb : pa);
+                if (kb - ka > 1) {                   // uniform: rows shorter than a slot, three pieces
+                    p = fo + T.pofs[0];
+#pragma unroll
+                    for (int k = 1; k < kMaxSeg; k++)
+                        if (T.qa[k] < T.qb[k] && fo >= T.rs[k])
+                            p = fo + T.pofs[k];
+                }
+                const f4 v = f4{O[p], O[p + 1], O[p + 2], O[p + 3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (unsigned)(4 * fo)));
+            }
+        }
+    };
+    __syncthreads();        // (prologue of the loader waves)
+    __syncthreads();
+    for (int q = 0; q < Q; q += 2) {
+        const int f = f0 + (q >> 1);
+        f2 acc[kP];
+        row_pass(T0, buf0, acc);
+        __syncthreads();                                                // A
+        write_O(T0, buf0, acc);
+        __syncthreads();                                                // B
+        copy_out_c(T0, buf0, f);
+        __syncthreads();                                                // C
+        row_pass(T1, buf1, acc);
+        __syncthreads();
+        write_O(T1, buf1, acc);
+        __syncthreads();
+        copy_out_c(T1, buf1, f);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------ column pass
+constexpr int kColRows = 64, kColCols = 64;              // outputs per step: 8 row groups x 32 column pairs
+constexpr int kColStride = kColCols + 2;                 // floats per staged row
+
+__global__ void __launch_bounds__(256, 3)
+col_march_f32_kernel(const float *__restrict__ tmp, float *__restrict__ dst, int h, int rw, int ncolt,
+                     TapsF32 taps)
+{
+    extern __shared__ float tile[];     // (64 + 2r) rows x 64 samples; row j <-> image row y0 - r + j
+    const int r = taps.ksize >> 1;
+    const int tid = threadIdx.x;
+    const int ct = blockIdx.x % ncolt;
+    const size_t fz = blockIdx.x / ncolt;
+    const int x0 = ct * kColCols;
+    const float *frame = tmp + fz * (size_t)h * rw;
+    float *oframe = dst + fz * (size_t)h * rw;
+    const int nrows = kColRows + 2 * r;
+
+    // BORDER_REFLECT_101 of a row index: one reflection covers every row a step can ask for
+    // unless the frame is shorter than the tile (then: the general periodic form)
+    const int period = h > 1 ? 2 * (h - 1) : 1;
+    auto reflect_row = [&](int yin) -> int {
+        int y = yin < 0 ? -yin : yin;
+        y = y >= h ? period - y : y;
+        if (__builtin_expect(y < 0 || y >= h, 0)) {
+            int m = yin % period;
+            m = m < 0 ? m + period : m;
+            y = m < h ? m : period - m;
+        }
+        return y;
+    };
+    // 4 samples of image row reflect(y); rw % 4 == 0, and a strip's last columns past the row
+    // end read (unused) samples from the row's last float4 instead
+    auto load4 = [&](int y, int c4) -> f4 {
+        const float *g = frame + (size_t)reflect_row(y) * rw + min(x0 + c4, rw - 4);
+        return __builtin_nontemporal_load(reinterpret_cast<const f4 *>(g));
+    };
+    auto put4 = [&](int row, int c4, f4 v) {
+        float *d = tile + row * kColStride + c4;
+        *reinterpret_cast<f2 *>(d) = f2{v.x, v.y};
+        *reinterpret_cast<f2 *>(d + 2) = f2{v.z, v.w};
+    };
+
+    // first tile: rows -r .. 63 + r
+    {
+        const int items = nrows * (kColCols / 4);
+        for (int base = 0; base < items; base += 4 * 256) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = min(base + u * 256 + tid, items - 1);
+                v[u] = load4(-r + (idx >> 4), (idx & 15) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + u * 256 + tid;
+                if (idx < items)
+                    put4(idx >> 4, (idx & 15) * 4, v[u]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int cp = tid & 31, rg = tid >> 5;
+    const int col = x0 + 2 * cp;
+    constexpr int RS = kColStride / 2;                                // row stride in f2
+    const int tr0_init = 8 * rg + r;                                 // tile row of output j = 0
+
+    for (int y0 = 0; y0 < h; y0 += kColRows) {
+        // the tile addresses below do not depend on y0; hidden from the optimiser, which would
+        // otherwise keep every (row group, tap) address of the step in a register across steps
+        int tr0 = tr0_init;
+        asm volatile("" : "+v"(tr0));
+        int toff = cp;
+        asm volatile("" : "+v"(toff));
+        const f2 *tcol = reinterpret_cast<const f2 *>(tile) + toff;
+        // the 64 rows the next step adds: image rows y0 + 64 + r .. y0 + 127 + r
+        const bool more = y0 + kColRows < h;
+        f4 pf[4];
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = u * 256 + tid;                        // 64 rows x 16 float4
+                pf[u] = load4(y0 + kColRows + r + (idx >> 4), (idx & 15) * 4);
+            }
+        }
+        // ---- centre tap, then symmetric pairs streaming outwards (two 8-row rings) -----------
+        if (col < rw) {
+            f2 up[8], dn[8], acc[8];
+            {
+                const f2 wc = f2{taps.t[r], taps.t[r]};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    up[j] = dn[j] = tcol[(tr0 + j) * RS];
+                    acc[j] = pk_fma(up[j], wc, f2{0.0f, 0.0f});
+                }
+            }
+            // Full groups of 8 taps, branch-free (k0 = 1 (mod 8): every ring slot below is static).
+            // Tap t of a group replaces ring slot t of `up` (row y+7+k for row y+k-1) and slot 7-t
+            // of `dn` (row y-k for row y+8-k); after the eighth tap the whole ring has been
+            // replaced.  So the eight arriving rows are kept in a second array, each use picks
+            // old or new by slot (static after unrolling), and the two arrays swap roles for the
+            // next group: no register moves at all.
+            auto group = [&](f2 (&ru)[8], f2 (&nu_)[8], f2 (&rd)[8], f2 (&nd_)[8], int kg) {
+                float wk8[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    wk8[t] = taps.t[r + kg + t];
+                    nu_[t] = tcol[(tr0 + 7 + kg + t) * RS];
+                    nd_[7 - t] = tcol[(tr0 - kg - t) * RS];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const f2 w2 = f2{wk8[t], wk8[t]};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int su = (j + 1 + t) % 8, sd = (j + 7 - t) % 8;
+                        const f2 U = su <= t ? nu_[su] : ru[su];
+                        const f2 D = (7 - sd) <= t ? nd_[sd] : rd[sd];
+                        acc[j] = pk_fma(U + D, w2, acc[j]);
+                    }
+                }
+            };
+            f2 nu[8], nd[8];
+            int k0 = 1;
+            for (; k0 + 15 <= r; k0 += 16) {
+                group(up, nu, dn, nd, k0);
+                group(nu, up, nd, dn, k0 + 8);
+            }
+            if (k0 + 7 <= r) {                                  // uniform: an odd number of full groups
+                group(up, nu, dn, nd, k0);
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    up[t] = nu[t];
+                    dn[t] = nd[t];
+                }
+                k0 += 8;
+            }
+            // the last r % 8 taps
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                if (k0 + t <= r) {                              // uniform
+                    up[t] = tcol[(tr0 + 7 + k0 + t) * RS];
+                    dn[7 - t] = tcol[(tr0 - k0 - t) * RS];
+                    const float wk = taps.t[r + k0 + t];
+                    const f2 w2 = f2{wk, wk};
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        acc[j] = pk_fma(up[(j + 1 + t) % 8] + dn[(j + 7 - t) % 8], w2, acc[j]);
+                }
+            }
+            const int yb = y0 + 8 * rg;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (yb + j < h) {
+                    float *o = oframe + (size_t)(yb + j) * rw + col;
+                    if (col + 1 < rw && (rw % 2 == 0))
+                        __builtin_nontemporal_store(acc[j], reinterpret_cast<f2 *>(o));
+                    else {
+                        o[0] = acc[j].x;
+                        if (col + 1 < rw)
+                            o[1] = acc[j].y;
+                    }
+                }
+            }
+        }
+        if (!more)
+            break;
+        __syncthreads();                                   // every read of this step's tile is done
+        // ---- slide: tile rows [64, 64 + 2r) become rows [0, 2r) ---------------------------------
+        if (2 * r * (kColCols / 2) <= 9 * 256) {           // uniform; r <= 36: every source row is read
+            constexpr int kMv = 9;                         // into registers before the first one is
+            f2 mv[kMv];                                    // overwritten: two barriers per step
+            const int items = 2 * r * (kColCols / 2);
+#pragma unroll
+            for (int u = 0; u < kMv; u++) {
+                const int idx = u * 256 + tid;
+                if (idx < items)
+                    mv[u] = reinterpret_cast<const f2 *>(tile)[(kColRows + (idx >> 5)) * RS + (idx & 31)];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kMv; u++) {
+                const int idx = u * 256 + tid;
+                if (idx < items)
+                    reinterpret_cast<f2 *>(tile)[(idx >> 5) * RS + (idx & 31)] = mv[u];
+            }
+        } else {                                           // larger radii: 64 rows at a time
+            for (int c0 = 0; c0 < 2 * r; c0 += kColRows) {
+                const int rows = min(kColRows, 2 * r - c0);
+                f2 mv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int idx = u * 256 + tid;         // 64 rows x 32 f2
+                    if ((idx >> 5) < rows)
+                        mv[u] = reinterpret_cast<const f2 *>(tile)[(c0 + kColRows + (idx >> 5)) * RS + (idx & 31)];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int idx = u * 256 + tid;
+                    if ((idx >> 5) < rows)
+                        reinterpret_cast<f2 *>(tile)[(c0 + (idx >> 5)) * RS + (idx & 31)] = mv[u];
+                }
+                if (c0 + kColRows < 2 * r)
+                    __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = u * 256 + tid;
+            put4(2 * r + (idx >> 4), (idx & 15) * 4, pf[u]);
+        }
+        __syncthreads();
+    }
+}
+
+// chunk length for the row kernel: every CU the same work when the frame allows it
+bool plan_rows(int h, int w, int c, const TapsF32 &taps, int slots, RowPlan *plan)
+{
+    const int r = taps.ksize / 2, halo = r * c, rw = w * c;
+    if ((c != 1 && c != 3) || w <= r || rw % 4 != 0 || kP % c != 0)
+        return false;
+    const long long total = (long long)h * rw;
+    long long L = ((total + slots - 1) / slots + 3) / 4 * 4;
+    auto fits = [&](long long len) {
+        const int ns = max_segments(len, rw);
+        return ns <= kMaxSeg && len + (long long)ns * 2 * halo <= 2LL * kHalfCap &&
+               (len + 2 * halo + 8) / 4 <= (long long)kNV * kT;
+    };
+    if (L < 1024)
+        L = total < 1024 ? (total + 3) / 4 * 4 : 1024;
+    while (L > 4 && !fits(L))
+        L -= 4;
+    if (!fits(L) || L < 4 * c)
+        return false;
+    plan->L = (int)L;
+    plan->nchunks = (int)((total + L - 1) / L);
+    return true;
+}
+
+}  // namespace
+
+bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps)
+{
+    RowPlan p;
+    const int r = taps.ksize / 2;
+    if (r > 60)          // the marching column tile must fit 64 KB of LDS four times per CU
+        return false;
+    return plan_rows(h, w, c, taps, 1024, &p);
+}
+
+// bg == nullptr: plain blur of the frames; otherwise EMA background subtraction first
+int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *bg, int64_t n_seen,
+                           double rate, int n, int h, int w, int c, const TapsF32 &taps, hipStream_t st,
+                           StageProfiler *prof)
+{
+    RowPlan plan;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    VA_REQUIRE(plan_rows(h, w, c, taps, 4 * cus, &plan), "fused float gaussian: unsupported shape");
+    VA_REQUIRE(reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(scratch) % 16 == 0 &&
+                   (!bg || reinterpret_cast<uintptr_t>(bg) % 16 == 0),
+               "fused float gaussian: buffers must be 16-byte aligned");
+    if (n == 0 || h == 0)
+        return VA_OK;
+    const int r = taps.ksize / 2, rw = w * c;
+    const size_t lds1 = 2 * (size_t)(kHalfCap + (taps.ksize - 1) * c + kP + 8) * sizeof(f2) +
+                        2 * (size_t)kNV * kT * sizeof(unsigned short);
+    const int nwg = (plan.nchunks + 1) / 2;          // two sub-chunks per workgroup
+    if (bg) {
+        if (c == 1)
+            ema_row_f32_kernel<1, true><<<nwg, 2 * kT, lds1, st>>>(src, scratch, bg, n_seen, (float)rate, n, h, w, plan.L, taps);
+        else
+            ema_row_f32_kernel<3, true><<<nwg, 2 * kT, lds1, st>>>(src, scratch, bg, n_seen, (float)rate, n, h, w, plan.L, taps);
+    } else {
+        const dim3 grid((unsigned)nwg, (unsigned)n);
+        if (c == 1)
+            ema_row_f32_kernel<1, false><<<grid, 2 * kT, lds1, st>>>(src, scratch, nullptr, 0, 0.f, n, h, w, plan.L, taps);
+        else
+            ema_row_f32_kernel<3, false><<<grid, 2 * kT, lds1, st>>>(src, scratch, nullptr, 0, 0.f, n, h, w, plan.L, taps);
+    }
+    VA_LAUNCH_CHECK("ema_row_f32_kernel");
+    if (prof)
+        prof->mark(bg ? "ema_row_f32" : "row_f32", st);
+    const int ncolt = cdiv(rw, kColCols);
+    const size_t lds2 = (size_t)(kColRows + 2 * r) * kColStride * sizeof(float);
+    col_march_f32_kernel<<<(unsigned)((size_t)ncolt * n), 256, lds2, st>>>(scratch, dst, h, rw, ncolt, taps);
+    VA_LAUNCH_CHECK("col_march_f32_kernel");
+    if (prof)
+        prof->mark("col_f32", st);
+    return VA_OK;
+}
+
+}  // namespace va
