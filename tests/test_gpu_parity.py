@@ -886,3 +886,101 @@ def test_contour_moments_match_oracle_bit_for_bit(ops, oracle):
     pts, area, count, mom = ops.largest_contour(m, moments=True)
     assert count == 2 and area == ref["m00"]
     assert np.array_equal(mom, [ref[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03")])
+
+
+def test_gpu_filter_chains_contract_into_one_engine(oracle):
+    """consecutive GPU filters collapse into one FrameEngine with batched prefetch (the reference's
+    own idiom for consecutive crops, video/filters.py:209-215 there): identical frames with and
+    without the contraction, listeners of every stage still notified, random access, partial
+    chains, and chains that must NOT contract (a listener on a stage whose frames the fused
+    chain never materialises)"""
+    from video import filters as F
+    from video.io.memory import VideoMemory
+    clip = _blob_clip(70, 72, 96, seed=12, salt=0.003)
+    rm, _, _, _ = oracle.chain_u8(clip, 2.0, 20, morph_ksize=5, connectivity=4)
+    rdiff, _ = oracle.bg_mean_u8(clip)
+    rblur = oracle.gaussian_u8(rdiff, 2.0)
+
+    def build(listen=()):
+        src = VideoMemory(clip)
+        bg = F.FilterBackground(src)
+        blur = F.FilterBlur(bg, 2)
+        thr = F.FilterThreshold(blur, 20)
+        mor = F.FilterMorphology(thr, "close", 5)
+        seen = {}
+        for name, node in (("bg", bg), ("blur", blur), ("thr", thr), ("mor", mor)):
+            if name in listen:
+                seen[name] = []
+                node.register_listener(lambda f, lst=seen[name]: lst.append(np.array(f)))
+        return mor, blur, thr, bg, seen
+
+    # contracted: one engine, blur-stage and final listeners see their frames
+    mor, blur, thr, bg, seen = build(listen=("blur", "mor"))
+    assert mor._runner() is not None and mor._runner().engine.description.count("morph=2")
+    frames = [np.array(f) for f in mor]
+    assert np.array_equal(np.stack(frames), rm)
+    assert np.array_equal(np.stack(seen["mor"]), rm) and np.array_equal(np.stack(seen["blur"]), rblur)
+    assert np.array_equal(mor[41], rm[41]) and np.array_equal(mor[3], rm[3]) and np.array_equal(mor[-1], rm[-1])
+    mor.close()
+    # intermediate stages read on their own contract over what lies below them
+    mor, blur, thr, bg, _ = build()
+    assert np.array_equal(np.stack([np.array(f) for f in blur]), rblur)
+    assert np.array_equal(np.stack([np.array(f) for f in thr]), oracle.threshold_u8(rblur, 20))
+    assert bg._runner() is None and np.array_equal(np.stack([np.array(f) for f in bg]), rdiff)
+    mor.close()
+    # a listener on the threshold stage (mask before the morphology): no contraction, same frames
+    mor, blur, thr, bg, seen = build(listen=("thr",))
+    assert mor._runner() is None
+    assert np.array_equal(np.stack([np.array(f) for f in mor]), rm)
+    assert np.array_equal(np.stack(seen["thr"]), oracle.threshold_u8(rblur, 20))
+    # the switch: per-filter path on request, identical frames
+    F._GpuStage.contract = False
+    try:
+        mor2 = build()[0]
+        assert mor2._runner() is None
+        assert np.array_equal(np.stack([np.array(f) for f in mor2[::7]]), rm[::7])
+    finally:
+        F._GpuStage.contract = True
+    # static background + threshold without a blur; open instead of close; maxval != 255 stays apart
+    static = np.full(clip.shape[1:], 100.0)
+    t = F.FilterThreshold(F.FilterBackground(VideoMemory(clip), mode="static", background=static), 25)
+    assert t._runner() is not None
+    assert np.array_equal(np.stack([np.array(f) for f in t]),
+                          oracle.threshold_u8(oracle.bg_static_u8(clip, static), 25))
+    t1 = F.FilterMorphology(F.FilterThreshold(F.FilterBlur(VideoMemory(clip), 2), 110, maxval=1), "open", 3)
+    assert t1._runner() is None                      # maxval 1 under a morphology: per-filter path
+    m1 = oracle.threshold_u8(oracle.gaussian_u8(clip, 2.0), 110, 1)
+    m1 = oracle.morph_u8(oracle.morph_u8(m1, oracle.ERODE, oracle.RECT, 3), oracle.DILATE, oracle.RECT, 3)
+    assert np.array_equal(np.stack([np.array(f) for f in t1]), m1)
+
+
+def test_contracted_chain_speed_1080p():
+    """the four-filter chain over 256 x 1080p frames, read frame by frame, must cost about what
+    FilterAnalysisChain costs (one engine pass per 32 frames either way): within 1.5x"""
+    import time
+    from video import filters as F
+    from video.io.memory import VideoMemory
+    clip = _blob_clip(32, 1080, 1920, seed=5, nblobs=20, salt=0.002)
+    clip = np.concatenate([clip] * 8)                      # 256 frames
+    def run(video):
+        t0 = time.perf_counter()
+        acc = 0
+        for f in video:
+            acc += int(f[540, 960])
+        return time.perf_counter() - t0, acc
+    fused = F.FilterAnalysisChain(VideoMemory(clip), sigma=5.0, threshold=20, connectivity=0, batch=32)
+    run(fused)                                             # warm-up (engine creation, first touch)
+    t_fused, a = run(fused)
+    chain = F.FilterMorphology(F.FilterThreshold(F.FilterBlur(F.FilterBackground(VideoMemory(clip)), 5), 20), "close", 5)
+    run(chain)
+    t_chain, b = run(chain)
+    F._GpuStage.contract = False
+    try:
+        plain = F.FilterMorphology(F.FilterThreshold(F.FilterBlur(F.FilterBackground(VideoMemory(clip[:32])), 5), 20), "close", 5)
+        t_plain, _ = run(plain)
+    finally:
+        F._GpuStage.contract = True
+    print("\n[chain contraction] 256 x 1080p: FilterAnalysisChain %.3f s, four contracted filters %.3f s, "
+          "uncontracted %.3f s per 256 frames" % (t_fused, t_chain, t_plain * 8))
+    assert a == b
+    assert t_chain < 1.5 * t_fused + 0.05

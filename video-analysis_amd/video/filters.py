@@ -17,7 +17,7 @@ import numpy as np
 from . import ops
 from .analysis.regions import rect_to_slices
 from .engine import FrameEngine
-from .io.base import VideoFilterBase
+from .io.base import VideoBase, VideoFilterBase
 
 logger = logging.getLogger("video")
 
@@ -159,7 +159,163 @@ class FilterMonochrome(VideoFilterBase):
         return super(FilterMonochrome, self)._process_frame(frame)
 
 
-class FilterBlur(VideoFilterBase):
+class _GpuStage(object):
+    """Mixin of the filters whose pixel work is a stage of `FrameEngine`'s fused chain
+    (FilterBackground -> FilterBlur -> FilterThreshold -> FilterMorphology).
+
+    Consecutive stages CONTRACT: when such a filter is read and its source is another stage, the
+    whole run of stages is executed by one engine on batches of frames of the first non-stage
+    source, instead of one upload / kernel / download round trip per filter and frame -- the
+    reference's own idiom for consecutive crops (video/filters.py:209-215 there), applied to the
+    GPU filters.  Results are identical (same kernels, same arithmetic).  Listeners of every
+    stage are still notified; a stage whose frames the engine does not materialise (the
+    difference image under a blur, the mask under a morphology) and that has listeners keeps
+    the chain uncontracted."""
+
+    contract = True          # class-wide switch (tests compare both paths)
+    chain_batch = 32         # frames per engine pass
+
+    def _stage(self):
+        """(kind, parameters) of this filter as a stage of the engine"""
+        raise NotImplementedError
+
+    def _chain_plan(self):
+        """engine arguments for the run of stages ending here, or None when it does not contract"""
+        stages, node = [], self
+        while isinstance(node, _GpuStage):
+            stages.append(node)
+            node = node._source
+        stages.reverse()
+        root = node
+        if not self.contract or len(stages) < 2 or root.is_color:
+            return None
+        order = {"background": 0, "blur": 1, "threshold": 2, "morphology": 3}
+        kinds = [st._stage()[0] for st in stages]
+        ranks = [order[k] for k in kinds]
+        if ranks != sorted(ranks) or any(kinds.count(k) > 1 for k in ("background", "blur", "threshold")):
+            return None
+        if "morphology" in kinds and "threshold" not in kinds:
+            return None                     # the engine's morphology works on thresholded masks
+        args = dict(background=None, rate=0.02, sigma=0.0, threshold=None, morphology=(),
+                    connectivity=0, static_background=None)
+        maxval = 255
+        steps = []
+        for st in stages:
+            kind, par = st._stage()
+            if kind == "background":
+                args.update(background=par["mode"], rate=par["rate"], static_background=par["background"])
+            elif kind == "blur":
+                args["sigma"] = par["sigma"]
+            elif kind == "threshold":
+                args["threshold"], maxval = par["threshold"], par["maxval"]
+            else:
+                steps += par["steps"]
+        if len(steps) > 4 or ("morphology" in kinds and maxval != 255) or (args["sigma"] and args["sigma"] <= 0):
+            return None
+        args["morphology"] = tuple(steps)
+        # what the engine materialises: 'filtered' = frames before the threshold, 'mask' = final mask
+        masks = "threshold" in kinds
+        pre = [st for st, k in zip(stages, kinds) if k in ("background", "blur")]
+        provides = {}
+        if pre:
+            provides[id(pre[-1])] = "filtered"
+        if masks:
+            provides[id(stages[-1])] = "mask"
+        if id(self) not in provides:
+            return None
+        for st in stages[:-1]:
+            if st._listeners and id(st) not in provides:
+                return None                 # its frames never exist in the fused chain
+        return dict(root=root, args=args, maxval=maxval, output=provides[id(self)],
+                    notify=[(st, provides[id(st)]) for st in stages[:-1] if st._listeners])
+
+    def _runner(self):
+        plan = self._chain_plan()
+        key = None if plan is None else (id(plan["root"]), repr(sorted(plan["args"].items(), key=str)),
+                                         plan["maxval"], plan["output"],
+                                         tuple(id(st) for st, _ in plan["notify"]))
+        if key != getattr(self, "_runner_key", "unset"):
+            old = getattr(self, "_runner_obj", None)
+            if old is not None:
+                old.close(propagate=False)
+            self._runner_obj = None
+            if plan is not None:
+                a = plan["args"]
+                extra = tuple(sorted({kind for _, kind in plan["notify"]} - {plan["output"]}))
+                self._runner_obj = FilterAnalysisChain(
+                    plan["root"], background=a["background"], rate=a["rate"], sigma=a["sigma"],
+                    threshold=a["threshold"], morphology=a["morphology"], connectivity=0,
+                    output=plan["output"], batch=self.chain_batch, extra_outputs=extra,
+                    static_background=a["static_background"])
+                self._runner_obj._engine_args["maxval"] = plan["maxval"]
+                self._runner_notify = plan["notify"]
+            self._runner_key = key
+        return self._runner_obj
+
+    def _contracted_frame(self, runner, index):
+        try:
+            frame = runner.get_frame(index)
+        except TypeError:                   # frames the engine does not take (not uint8): per-filter path
+            _GpuStage._disable(self)
+            return None
+        for stage, kind in self._runner_notify:
+            VideoBase._process_frame(stage, runner.last_results[kind])
+        return VideoBase._process_frame(self, frame)
+
+    def _disable(self):
+        self.contract = False
+        self._runner()
+
+    def get_frame(self, index):
+        runner = self._runner()
+        if runner is not None:
+            if index < 0:
+                index += self.frame_count
+            if not 0 <= index < self.frame_count:
+                raise IndexError("frame %d is out of range" % index)
+            out = self._contracted_frame(runner, index)
+            if out is not None:
+                self._frame_pos = index
+                return out
+        return super(_GpuStage, self).get_frame(index)
+
+    def get_next_frame(self):
+        runner = self._runner()
+        if runner is not None:
+            if self._frame_pos >= self.frame_count:
+                raise StopIteration
+            out = self._contracted_frame(runner, self._frame_pos)
+            if out is not None:
+                self._frame_pos += 1
+                return out
+            self._source.set_frame_pos(self._frame_pos)
+        return super(_GpuStage, self).get_next_frame()
+
+    def set_frame_pos(self, index):
+        if self._runner() is not None:
+            if index < 0:
+                index += self.frame_count
+            if not 0 <= index < self.frame_count:
+                raise IndexError("Seeking to frame %d was not possible." % index)
+            self._frame_pos = index
+            return
+        super(_GpuStage, self).set_frame_pos(index)
+
+    def get_frame_pos(self):
+        if self._runner() is not None:
+            return self._frame_pos
+        return super(_GpuStage, self).get_frame_pos()
+
+    def close(self, propagate=True):
+        old = getattr(self, "_runner_obj", None)
+        if old is not None:
+            old.close(propagate=False)
+            self._runner_obj = None
+            self._runner_key = None
+        super(_GpuStage, self).close(propagate)
+
+
+class FilterBlur(_GpuStage, VideoFilterBase):
     """Gaussian blur of standard deviation `sigma` (reference :378-392:
     cv2.GaussianBlur(frame.astype(np.uint8), (0, 0), sigma)).  Unlike the reference
      listeners ARE notified."""
@@ -168,13 +324,16 @@ class FilterBlur(VideoFilterBase):
         self.sigma = sigma
         super(FilterBlur, self).__init__(source)
 
+    def _stage(self):
+        return "blur", {"sigma": float(self.sigma)}
+
     def _process_frame(self, frame):
         frame = np.asarray(frame).astype(np.uint8)          # C truncation/wrap like the reference
         out = ops.gaussian_blur(frame, self.sigma, color=frame.ndim == 3)
         return super(FilterBlur, self)._process_frame(out)
 
 
-class FilterThreshold(VideoFilterBase):
+class FilterThreshold(_GpuStage, VideoFilterBase):
     """BUILD-DEFINED: binary threshold `frame > threshold ? maxval : 0` on uint8 frames
     (the reference builds such masks with NumPy comparisons, video/analysis/image.py:282-304)"""
 
@@ -184,6 +343,9 @@ class FilterThreshold(VideoFilterBase):
             raise ValueError("maxval must be in [0, 255]")
         super(FilterThreshold, self).__init__(source)
 
+    def _stage(self):
+        return "threshold", {"threshold": self.threshold, "maxval": self.maxval}
+
     def _process_frame(self, frame):
         frame = np.asarray(frame)
         if frame.dtype != np.uint8:
@@ -192,7 +354,7 @@ class FilterThreshold(VideoFilterBase):
             ops.threshold(frame, self.threshold, self.maxval))
 
 
-class FilterMorphology(VideoFilterBase):
+class FilterMorphology(_GpuStage, VideoFilterBase):
     """BUILD-DEFINED: erode / dilate / open / close with a `ksize` x `ksize` structuring
     element of `shape` in {'rect','cross','ellipse'} (primitive: cv2.erode/cv2.dilate as used at
     video/analysis/image.py:248-251)"""
@@ -215,6 +377,9 @@ class FilterMorphology(VideoFilterBase):
     @property
     def steps(self):
         return [(op, self.element, self.ksize) for op in self._SEQUENCES[self.operation]]
+
+    def _stage(self):
+        return "morphology", {"steps": self.steps}
 
     def _process_frame(self, frame):
         frame = np.asarray(frame)
@@ -425,7 +590,7 @@ class _SequentialStateFilter(VideoFilterBase):
         return self._process_frame(out)
 
 
-class FilterBackground(_SequentialStateFilter):
+class FilterBackground(_GpuStage, _SequentialStateFilter):
     """BUILD-DEFINED running background subtraction.
 
     frame k -> sat_u8(trunc(|frame_k - bg_{k-1}|)), then the model is updated with frame k.
@@ -465,6 +630,9 @@ class FilterBackground(_SequentialStateFilter):
             raise TypeError("FilterBackground expects uint8 frames")
         return self._model.process(frame[None])[0]
 
+    def _stage(self):
+        return "background", {"mode": self.mode, "rate": self.rate, "background": self._background}
+
     @property
     def background(self):
         """current background model (float64 / float32 array)"""
@@ -489,7 +657,7 @@ class FilterAnalysisChain(_SequentialStateFilter):
 
     def __init__(self, source, background="mean", rate=0.02, sigma=5.0, threshold=20,
                  morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4,
-                 output="mask", batch=32, max_labels=0):
+                 output="mask", batch=32, max_labels=0, extra_outputs=(), static_background=None):
         if source.is_color:
             raise ValueError("FilterAnalysisChain expects a monochrome video")
         if output not in ("mask", "labels", "filtered"):
@@ -497,6 +665,9 @@ class FilterAnalysisChain(_SequentialStateFilter):
         if output == "labels" and not connectivity:
             raise ValueError("output='labels' needs connectivity 4 or 8")
         self.output = output
+        self.extra_outputs = tuple(extra_outputs)        # further per-frame results kept in last_results
+        self._static_background = static_background
+        self.last_results = {}
         self.batch = int(batch)
         self._engine_args = dict(size=source.size, channels=1, dtype=np.uint8, max_batch=self.batch,
                                  background=background, bg_rate=rate, sigma=sigma, thresh=threshold,
@@ -512,6 +683,8 @@ class FilterAnalysisChain(_SequentialStateFilter):
     def engine(self):
         if self._engine is None:
             self._engine = FrameEngine(**self._engine_args)
+            if self._engine_args["background"] == "static":
+                self._engine.set_background(self._static_background, 0)
         return self._engine
 
     @property
@@ -519,7 +692,7 @@ class FilterAnalysisChain(_SequentialStateFilter):
         return self._engine_args["background"] in ("mean", "ema")
 
     def _wanted(self):
-        want = {self.output}
+        want = {self.output} | set(self.extra_outputs)
         if self._engine_args["connectivity"]:
             want.add("counts")
         if self._engine_args["max_labels"] > 0:
@@ -527,7 +700,8 @@ class FilterAnalysisChain(_SequentialStateFilter):
         return want
 
     def _reset_state(self):
-        self.engine.set_background(None, 0)
+        if self._engine_args["background"] in ("mean", "ema"):
+            self.engine.set_background(None, 0)
         self._cache = {}
 
     def _advance_state(self, frames):
@@ -552,6 +726,7 @@ class FilterAnalysisChain(_SequentialStateFilter):
         r = self._cache[index]
         self.last_count = int(r["counts"]) if "counts" in r else None
         self.last_stats = r.get("stats")
+        self.last_results = r
         return r[self.output]
 
     def set_frame_pos(self, index):

@@ -11,6 +11,56 @@ import numpy as np
 from . import _hip
 from ._hip import DeviceBuffer, check
 
+# ------------------------------------------------------------------------ device-buffer pool
+# The per-call wrappers below run once per frame when filters are used one by one; a hipMalloc /
+# hipFree pair per operand and call (both synchronise the device) used to dominate them.  Buffers
+# are recycled by size class (powers of two) instead; the pool is bounded and trimmed on overflow.
+_POOL = {}
+_POOL_BYTES = 0
+POOL_CAPACITY = 4 << 30
+
+
+def _take(nbytes):
+    """a device buffer of at least `nbytes` bytes (recycled when one of its size class is free)"""
+    global _POOL_BYTES
+    size = max(256, 1 << max(int(nbytes) - 1, 1).bit_length())
+    free = _POOL.get(size)
+    if free:
+        _POOL_BYTES -= size
+        return free.pop()
+    return DeviceBuffer(size)
+
+
+def _upload(arr, stream=None):
+    arr = np.ascontiguousarray(arr)
+    buf = _take(arr.nbytes)
+    buf.upload(arr, stream)
+    return buf
+
+
+def _give(*bufs):
+    """hand buffers back (every call below has synchronised its stream by then)"""
+    global _POOL_BYTES
+    for b in bufs:
+        if b is None:
+            continue
+        if _POOL_BYTES + b.nbytes > POOL_CAPACITY:
+            b.free()
+            continue
+        _POOL.setdefault(b.nbytes, []).append(b)
+        _POOL_BYTES += b.nbytes
+
+
+def pool_clear():
+    """free every pooled buffer (tests; before handing the GPU to another library)"""
+    global _POOL_BYTES
+    for free in _POOL.values():
+        for b in free:
+            b.free()
+    _POOL.clear()
+    _POOL_BYTES = 0
+
+
 
 def _as_batch(arr, frame_ndim):
     """returns (contiguous array, n, frame_shape, was_single)"""
@@ -44,8 +94,8 @@ def gaussian_blur(frames, sigma, color=False, implementation=None):
     arr, n, fshape, single = _as_batch(frames, 3 if color else 2)
     h, w, c = _hwc(fshape)
     L = _hip.lib()
-    src = DeviceBuffer.from_array(arr)
-    dst = DeviceBuffer(arr.nbytes)
+    src = _upload(arr)
+    dst = _take(arr.nbytes)
     if arr.dtype == np.uint8:
         fn = {None: L.va_gaussian_u8, "generic": L.va_gaussian_u8_generic,
               "valu": L.va_gaussian_u8_valu}[implementation]
@@ -53,8 +103,8 @@ def gaussian_blur(frames, sigma, color=False, implementation=None):
         fn = L.va_gaussian_f32
     check(fn(src.ptr, dst.ptr, n, h, w, c, float(sigma), None))
     out = dst.download(arr.shape, arr.dtype)
-    src.free()
-    dst.free()
+    _give(src)
+    _give(dst)
     return out
 
 
@@ -81,7 +131,7 @@ class BackgroundModel(object):
             init = np.ascontiguousarray(background, self.state_dtype).reshape(self.frame_shape)
         elif self.mode == _hip.BG_STATIC:
             raise ValueError("mode='static' needs a background image")
-        self._state = DeviceBuffer.from_array(init)
+        self._state = _upload(init)
 
     def process(self, frames, want_diff=True):
         """fold `frames` (N, *frame_shape) in, return |frame - bg_prev| per frame"""
@@ -89,17 +139,17 @@ class BackgroundModel(object):
         if arr.shape[1:] != self.frame_shape:
             raise ValueError("frames of shape %r do not match %r" % (arr.shape[1:], self.frame_shape))
         n = arr.shape[0]
-        src = DeviceBuffer.from_array(arr)
-        dst = DeviceBuffer(arr.nbytes) if want_diff else None
+        src = _upload(arr)
+        dst = _take(arr.nbytes) if want_diff else None
         check(_hip.lib().va_bg_update(self.mode, _hip.VA_U8 if self.dtype == np.uint8 else _hip.VA_F32,
                                       src.ptr, dst.ptr if dst else None, self._state.ptr,
                                       self.n_seen, self.rate, n, self.px, None))
         if self.mode != _hip.BG_STATIC:
             self.n_seen += n
         out = dst.download(arr.shape, arr.dtype) if dst else None
-        src.free()
+        _give(src)
         if dst:
-            dst.free()
+            _give(dst)
         return out
 
     @property
@@ -118,13 +168,13 @@ def welford(frames, mean=None, m2=None, n_seen=0):
     px = int(np.prod(fshape))
     mean = np.zeros(fshape) if mean is None else np.ascontiguousarray(mean, np.float64)
     m2 = np.zeros(fshape) if m2 is None else np.ascontiguousarray(m2, np.float64)
-    src = DeviceBuffer.from_array(arr)
-    dm = DeviceBuffer.from_array(mean)
-    dq = DeviceBuffer.from_array(m2)
+    src = _upload(arr)
+    dm = _upload(mean)
+    dq = _upload(m2)
     check(_hip.lib().va_welford_u8(src.ptr, dm.ptr, dq.ptr, int(n_seen), arr.shape[0], px, None))
     out = dm.download(fshape, np.float64), dq.download(fshape, np.float64)
     for b in (src, dm, dq):
-        b.free()
+        _give(b)
     return out
 
 
@@ -134,22 +184,22 @@ def time_difference(this_frame, prev_frame):
     b = np.ascontiguousarray(prev_frame, np.uint8)
     if a.shape != b.shape:
         raise ValueError("frame shapes differ")
-    da, db = DeviceBuffer.from_array(a), DeviceBuffer.from_array(b)
-    do = DeviceBuffer(a.size * 2)
+    da, db = _upload(a), _upload(b)
+    do = _take(a.size * 2)
     check(_hip.lib().va_time_difference_u8(da.ptr, db.ptr, do.ptr, a.size, None))
     out = do.download(a.shape, np.int16)
     for x in (da, db, do):
-        x.free()
+        _give(x)
     return out
 
 
 def _pointwise_u8(fn, arr, out_shape, *args):
-    src = DeviceBuffer.from_array(arr)
-    dst = DeviceBuffer(int(np.prod(out_shape)))
+    src = _upload(arr)
+    dst = _take(int(np.prod(out_shape)))
     check(fn(src.ptr, dst.ptr, *args))
     out = dst.download(out_shape, np.uint8)
-    src.free()
-    dst.free()
+    _give(src)
+    _give(dst)
     return out
 
 
@@ -175,12 +225,12 @@ def rot90(frames, k=1, color=False):
     h, w, c = _hwc(fshape)
     k = int(k) % 4
     out_shape = ((w, h) if k & 1 else (h, w)) + ((c,) if color else ())
-    src = DeviceBuffer.from_array(arr)
-    dst = DeviceBuffer(arr.nbytes)
+    src = _upload(arr)
+    dst = _take(arr.nbytes)
     check(_hip.lib().va_rot90(src.ptr, dst.ptr, n, h, w, c * arr.dtype.itemsize, k, None))
     out = dst.download((n,) + out_shape, arr.dtype)
-    src.free()
-    dst.free()
+    _give(src)
+    _give(dst)
     return out[0] if single else out
 
 
@@ -211,16 +261,16 @@ def label(masks, connectivity=4):
     arr, n, fshape, single = _as_batch(m, 2)
     h, w = fshape
     L = _hip.lib()
-    src = DeviceBuffer.from_array(arr)
-    lab = DeviceBuffer(arr.size * 4)
-    cnt = DeviceBuffer(max(n, 1) * 4)
+    src = _upload(arr)
+    lab = _take(arr.size * 4)
+    cnt = _take(max(n, 1) * 4)
     ws_bytes = L.va_label_workspace_bytes(n, h, w)
-    ws = DeviceBuffer(ws_bytes)
+    ws = _take(ws_bytes)
     check(L.va_label_i32(src.ptr, lab.ptr, cnt.ptr, n, h, w, int(connectivity), ws.ptr, ws_bytes, None))
     labels = lab.download(arr.shape, np.int32)
     counts = cnt.download((n,), np.int32)
     for b in (src, lab, cnt, ws):
-        b.free()
+        _give(b)
     if single:
         return labels, int(counts[0])
     return labels, counts
@@ -231,12 +281,12 @@ def region_stats(labels, max_labels):
     arr, n, fshape, single = _as_batch(np.asarray(labels, np.int32), 2)
     h, w = fshape
     max_labels = max(int(max_labels), 1)
-    src = DeviceBuffer.from_array(arr)
-    st = DeviceBuffer(n * max_labels * _hip.STATS_STRIDE * 8)
+    src = _upload(arr)
+    st = _take(n * max_labels * _hip.STATS_STRIDE * 8)
     check(_hip.lib().va_moments_i64(src.ptr, n, h, w, max_labels, st.ptr, None))
     out = st.download((n, max_labels, _hip.STATS_STRIDE), np.int64)
-    src.free()
-    st.free()
+    _give(src)
+    _give(st)
     return out[0] if single else out
 
 
@@ -251,21 +301,21 @@ def largest_region(mask, connectivity=4):
     m = np.ascontiguousarray(m)
     h, w = m.shape
     L = _hip.lib()
-    src = DeviceBuffer.from_array(m)
-    lab = DeviceBuffer(m.size * 4)
-    cnt = DeviceBuffer(4)
+    src = _upload(m)
+    lab = _take(m.size * 4)
+    cnt = _take(4)
     ws_bytes = L.va_label_workspace_bytes(1, h, w)
-    ws = DeviceBuffer(ws_bytes)
+    ws = _take(ws_bytes)
     check(L.va_label_i32(src.ptr, lab.ptr, cnt.ptr, 1, h, w, int(connectivity), ws.ptr, ws_bytes, None))
     count = int(cnt.download((1,), np.int32)[0])
     bufs = [src, lab, cnt, ws]
     try:
         if count == 0:
             return np.zeros(m.shape, bool), 0, 0
-        st = DeviceBuffer(count * _hip.STATS_STRIDE * 8)
-        big = DeviceBuffer(4)
-        area = DeviceBuffer(8)
-        sel = DeviceBuffer(m.size)
+        st = _take(count * _hip.STATS_STRIDE * 8)
+        big = _take(4)
+        area = _take(8)
+        sel = _take(m.size)
         bufs += [st, big, area, sel]
         check(L.va_moments_i64(lab.ptr, 1, h, w, count, st.ptr, None))
         check(L.va_largest_region(lab.ptr, cnt.ptr, st.ptr, 1, h, w, count, big.ptr, area.ptr,
@@ -274,7 +324,7 @@ def largest_region(mask, connectivity=4):
         return out, int(area.download((1,), np.int64)[0]), count
     finally:
         for b in bufs:
-            b.free()
+            _give(b)
 
 
 def largest_contour(mask, max_points=None, moments=False):
@@ -291,14 +341,14 @@ def largest_contour(mask, max_points=None, moments=False):
     h, w = m.shape
     L = _hip.lib()
     cap = int(max_points) if max_points else 4096
-    src = DeviceBuffer.from_array(m)
+    src = _upload(m)
     ws_bytes = L.va_contour_workspace_bytes(1, h, w)
-    ws = DeviceBuffer(ws_bytes)
-    npts, area, ncomp = DeviceBuffer(4), DeviceBuffer(8), DeviceBuffer(4)
+    ws = _take(ws_bytes)
+    npts, area, ncomp = _take(4), _take(8), _take(4)
     bufs = [src, ws, npts, area, ncomp]
     try:
         while True:
-            pts = DeviceBuffer(cap * 8)
+            pts = _take(cap * 8)
             bufs.append(pts)
             check(L.va_largest_contour(src.ptr, 1, h, w, pts.ptr, cap, npts.ptr, area.ptr, ncomp.ptr,
                                        ws.ptr, ws_bytes, None))
@@ -310,14 +360,14 @@ def largest_contour(mask, max_points=None, moments=False):
         points = pts.download((min(n, cap), 2), np.int32)
         res = (points, float(area.download((1,), np.float64)[0]), count)
         if moments:
-            mom = DeviceBuffer(10 * 8)
+            mom = _take(10 * 8)
             bufs.append(mom)
             check(L.va_contour_moments(pts.ptr, npts.ptr, 1, cap, 0, mom.ptr, None))
             res += (mom.download((10,), np.float64),)
         return res
     finally:
         for b in bufs:
-            b.free()
+            _give(b)
 
 
 def contour_moments(contour):
@@ -330,14 +380,14 @@ def contour_moments(contour):
         raise ValueError("contour must hold (x, y) points")
     is_float = 0 if np.issubdtype(c.dtype, np.integer) else 1
     c = np.ascontiguousarray(c.reshape(-1, 2), np.float32 if is_float else np.int32)
-    pts = DeviceBuffer.from_array(c)
-    out = DeviceBuffer(10 * 8)
+    pts = _upload(c)
+    out = _take(10 * 8)
     try:
         check(_hip.lib().va_contour_moments(pts.ptr, None, 1, len(c), is_float, out.ptr, None))
         return out.download((10,), np.float64)
     finally:
-        pts.free()
-        out.free()
+        _give(pts)
+        _give(out)
 
 
 def detect_peaks(img, include_plateaus=True):
@@ -357,14 +407,14 @@ def mask_thinning(img):
     if a.ndim != 2:
         raise ValueError("mask must be 2-d")
     h, w = a.shape
-    cur, tmp, skel = DeviceBuffer.from_array(a), DeviceBuffer(a.size), DeviceBuffer(a.size)
+    cur, tmp, skel = _upload(a), _take(a.size), _take(a.size)
     it = C.c_int()
     try:
         check(_hip.lib().va_mask_thinning_u8(cur.ptr, tmp.ptr, skel.ptr, h, w, C.byref(it), None))
         return skel.download(a.shape, np.uint8), it.value
     finally:
         for b in (cur, tmp, skel):
-            b.free()
+            _give(b)
 
 
 def image_statistics(img, kernel="box", ksize=5, prior=0.0, exclude_center=False, ret_var=True):
@@ -374,9 +424,9 @@ def image_statistics(img, kernel="box", ksize=5, prior=0.0, exclude_center=False
     if a.dtype != np.uint8 or a.ndim != 2:
         raise TypeError("image_statistics expects a 2-d uint8 image on the GPU path")
     h, w = a.shape
-    src = DeviceBuffer.from_array(a)
-    dm = DeviceBuffer(a.size * 8)
-    dv = DeviceBuffer(a.size * 8) if ret_var else None
+    src = _upload(a)
+    dm = _take(a.size * 8)
+    dv = _take(a.size * 8) if ret_var else None
     try:
         check(_hip.lib().va_image_statistics_u8(src.ptr, dm.ptr, dv.ptr if dv else None, 1, h, w,
                                                 {"box": 0, "ellipse": 1, "circle": 1}[kernel],
@@ -387,4 +437,4 @@ def image_statistics(img, kernel="box", ksize=5, prior=0.0, exclude_center=False
     finally:
         for b in (src, dm, dv):
             if b:
-                b.free()
+                _give(b)
