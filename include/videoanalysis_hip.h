@@ -144,6 +144,20 @@ int va_normalize_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t count, doub
 int va_rot90(const void *src_dev, void *dst_dev, int n, int h, int w, int elem_bytes, int k,
              void *stream);
 
+/* replaces  cv2.resize(frame, self.size, interpolation=...), FilterResize._process_frame,
+ *           video/filters.py:310-314 (N4).  uint8 frames (n, src_h, src_w[, c]) -> (n, dst_h, dst_w[, c]),
+ * c <= 4 interleaved channels.  OpenCV's 8-bit definitions: nearest = floor(x * src/dst); linear and
+ * cubic (A = -0.75) with 11-bit fixed-point weights and OpenCV's rounding steps (an exact 2x2
+ * linear shrink is the area mean, as there); area = block means for integer shrink factors,
+ * float cell-overlap weights for other shrinks, linear with area-style positions when growing.
+ * INTER_LANCZOS4 is not provided.  src != dst. */
+#define VA_INTER_NEAREST 0
+#define VA_INTER_LINEAR 1
+#define VA_INTER_CUBIC 2
+#define VA_INTER_AREA 3
+int va_resize_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int src_h, int src_w, int c, int dst_h,
+                 int dst_w, int interpolation, void *stream);
+
 /* ------------------------------------------------------------------ A6 morphology
  * replaces  cv2.erode / cv2.dilate(img, cv2.getStructuringElement(shape, (k, k))),
  *           video/analysis/image.py:248-251; anchor = centre, pixels outside the image never

@@ -71,6 +71,7 @@ def lib():
                                                            C.c_int64, C.c_void_p, C.c_int]
         _lib.vao_contour_area.argtypes = [C.c_void_p, C.c_int]
         _lib.vao_contour_area.restype = C.c_double
+        _lib.vao_resize_u8.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7
         _lib.vao_contour_moments.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.vao_contour_moments.restype = None
         _lib.vao_chain_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -335,6 +336,29 @@ def contour_area(contour):
     """cv2.contourArea (video/analysis/regions.py:188)"""
     c = np.ascontiguousarray(np.asarray(contour).reshape(-1, 2), np.int32)
     return lib().vao_contour_area(_p(c), len(c))
+
+
+RESIZE_MODES = {"nearest": 0, "linear": 1, "cubic": 2, "area": 3}
+
+
+def resize_u8(frames, size, interpolation="linear", layout=None):
+    """cv2.resize(frame, (width, height), interpolation=...) per frame (FilterResize,
+    video/filters.py:310-314) for uint8 frames; size = (width, height)"""
+    a, n, h, w, c = _nhwc(np.asarray(frames, np.uint8), layout)
+    dw, dh = int(size[0]), int(size[1])
+    out = np.empty((n, dh, dw, c), np.uint8)
+    if lib().vao_resize_u8(_p(a), _p(out), n, h, w, c, dh, dw, RESIZE_MODES[interpolation]):
+        raise ValueError("resize failed")
+    shape = a.shape[:-3] + (dh, dw) + ((c,) if a.ndim == 4 or layout == "hwc" else ())
+    if a.ndim == 2:
+        shape = (dh, dw)
+    elif a.ndim == 3 and layout != "hwc":
+        shape = (n, dh, dw)
+    elif a.ndim == 3:
+        shape = (dh, dw, c)
+    else:
+        shape = (n, dh, dw, c)
+    return out.reshape(shape)
 
 
 MOMENT_KEYS = ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03",

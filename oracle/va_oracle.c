@@ -838,3 +838,257 @@ void vao_contour_moments(const void *pts, int n, int is_float, double *out)
         out[9] = a03 * db1_20;
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * N4  cv2.resize(frame, size, interpolation=...)  -- FilterResize._process_frame,
+ *     video/filters.py:310-314 (modes chosen at :274-293; 'auto' = INTER_AREA when the frame
+ *     shrinks, INTER_CUBIC when it grows).  uint8 frames, c interleaved channels.
+ * Restates OpenCV's resize (modules/imgproc/src/resize.cpp) as published for 8-bit images:
+ *   NEAREST  sx = min(floor(dx * (1/inv_scale_x)), sw-1)
+ *   LINEAR   fx = (dx+0.5)*scale_x - 0.5 in float; 11-bit fixed-point coefficients
+ *            (saturate_cast<short>(c * 2048)); horizontal sums in int; vertical
+ *            ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2; an exact 2x2 shrink is AREA
+ *   CUBIC    A = -0.75 coefficients in float, 11-bit fixed point, replicated border,
+ *            (sum + 2^21) >> 22
+ *   AREA     shrink by integer factors: block mean ((sum+2)>>2 for 2x2, else
+ *            saturate_cast<uchar>(sum * (1.f/area))); other shrinks: float cell-overlap tables
+ *            (computeResizeAreaTab order); growing: LINEAR with area-style positions
+ * mode: 0 nearest, 1 linear, 2 cubic, 3 area.  Parity with real OpenCV: unpinned (no cv2 here).
+ * ---------------------------------------------------------------------------------- */
+static int vao_round_half_even(double v) { return (int)nearbyint(v); }
+static short vao_sat_short(float v)
+{
+    int r = (int)nearbyintf(v);
+    return (short)(r < -32768 ? -32768 : r > 32767 ? 32767 : r);
+}
+static uint8_t vao_sat_u8i(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+static void vao_cubic_coeffs(float x, float *c)
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+typedef struct { int si, di; float alpha; } vao_dec_alpha;
+static int vao_area_tab(int ssize, int dsize, double scale, vao_dec_alpha *tab)
+{
+    int k = 0;
+    for (int dx = 0; dx < dsize; dx++) {
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        if (sx1 - fsx1 > 1e-3) {
+            tab[k].di = dx, tab[k].si = sx1 - 1;
+            tab[k++].alpha = (float)((sx1 - fsx1) / cell);
+        }
+        for (int sx = sx1; sx < sx2; sx++) {
+            tab[k].di = dx, tab[k].si = sx;
+            tab[k++].alpha = (float)(1.0 / cell);
+        }
+        if (fsx2 - sx2 > 1e-3) {
+            double m = fsx2 - sx2 < 1. ? fsx2 - sx2 : 1.;
+            m = m < cell ? m : cell;
+            tab[k].di = dx, tab[k].si = sx2;
+            tab[k++].alpha = (float)(m / cell);
+        }
+    }
+    return k;
+}
+
+int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw,
+                  int mode)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || c <= 0 || mode < 0 || mode > 3)
+        return -1;
+    const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+    const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+    const size_t sfs = (size_t)sh * sw * c, dfs = (size_t)dh * dw * c;
+    if (mode == 0) {
+        const double ifx = 1. / inv_sx, ify = 1. / inv_sy;
+        for (int f = 0; f < n; f++)
+            for (int y = 0; y < dh; y++) {
+                int sy = (int)floor(y * ify);
+                if (sy > sh - 1) sy = sh - 1;
+                for (int x = 0; x < dw; x++) {
+                    int sx = (int)floor(x * ifx);
+                    if (sx > sw - 1) sx = sw - 1;
+                    for (int k = 0; k < c; k++)
+                        dst[f * dfs + ((size_t)y * dw + x) * c + k] = src[f * sfs + ((size_t)sy * sw + sx) * c + k];
+                }
+            }
+        return 0;
+    }
+    int iscale_x = (int)nearbyint(scale_x), iscale_y = (int)nearbyint(scale_y);   /* saturate_cast<int> */
+    const int area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    if (mode == 1 && area_fast && iscale_x == 2 && iscale_y == 2)
+        mode = 3;
+    if (mode == 3 && scale_x >= 1 && scale_y >= 1) {
+        if (area_fast) {
+            const int area = iscale_x * iscale_y;
+            const float scale = 1.f / area;
+            int wfull = (int)(sw / scale_x);
+            if (wfull > dw) wfull = dw;
+            for (int f = 0; f < n; f++)
+                for (int y = 0; y < dh; y++) {
+                    const int sy0 = y * iscale_y;
+                    for (int x = 0; x < dw; x++)
+                        for (int k = 0; k < c; k++) {
+                            const int sx0 = x * iscale_x;
+                            uint8_t out;
+                            if (sy0 + iscale_y <= sh && x < wfull) {
+                                int sum = 0;
+                                for (int yy = 0; yy < iscale_y; yy++)
+                                    for (int xx = 0; xx < iscale_x; xx++)
+                                        sum += src[f * sfs + ((size_t)(sy0 + yy) * sw + sx0 + xx) * c + k];
+                                if (iscale_x == 2 && iscale_y == 2)
+                                    out = (uint8_t)((sum + 2) >> 2);
+                                else
+                                    out = vao_sat_u8i((int)nearbyintf(sum * scale));
+                            } else {
+                                int sum = 0, count = 0;
+                                for (int yy = 0; yy < iscale_y && sy0 + yy < sh; yy++)
+                                    for (int xx = 0; xx < iscale_x && sx0 + xx < sw; xx++) {
+                                        sum += src[f * sfs + ((size_t)(sy0 + yy) * sw + sx0 + xx) * c + k];
+                                        count++;
+                                    }
+                                out = vao_sat_u8i((int)nearbyintf((float)sum / count));
+                            }
+                            dst[f * dfs + ((size_t)y * dw + x) * c + k] = out;
+                        }
+                }
+            return 0;
+        }
+        vao_dec_alpha *xt = (vao_dec_alpha *)malloc(sizeof(vao_dec_alpha) * (size_t)(sw * 2 + dw * 2 + 4));
+        vao_dec_alpha *yt = (vao_dec_alpha *)malloc(sizeof(vao_dec_alpha) * (size_t)(sh * 2 + dh * 2 + 4));
+        const int nx = vao_area_tab(sw, dw, scale_x, xt), ny = vao_area_tab(sh, dh, scale_y, yt);
+        float *buf = (float *)malloc(sizeof(float) * (size_t)dw * c), *sum = (float *)malloc(sizeof(float) * (size_t)dw * c);
+        for (int f = 0; f < n; f++) {
+            int prev_dy = yt[0].di;
+            for (int i = 0; i < dw * c; i++) sum[i] = 0.f;
+            for (int j = 0; j < ny; j++) {
+                const float beta = yt[j].alpha;
+                const int dy = yt[j].di, sy = yt[j].si;
+                const uint8_t *S = src + f * sfs + (size_t)sy * sw * c;
+                for (int i = 0; i < dw * c; i++) buf[i] = 0.f;
+                for (int k = 0; k < nx; k++)
+                    for (int ch = 0; ch < c; ch++) {
+                        const float p = S[xt[k].si * c + ch] * xt[k].alpha;
+                        buf[xt[k].di * c + ch] += p;
+                    }
+                if (dy != prev_dy) {
+                    uint8_t *D = dst + f * dfs + (size_t)prev_dy * dw * c;
+                    for (int i = 0; i < dw * c; i++) {
+                        D[i] = vao_sat_u8i((int)nearbyintf(sum[i]));
+                        sum[i] = beta * buf[i];
+                    }
+                    prev_dy = dy;
+                } else {
+                    for (int i = 0; i < dw * c; i++) {
+                        const float p = beta * buf[i];
+                        sum[i] += p;
+                    }
+                }
+            }
+            uint8_t *D = dst + f * dfs + (size_t)prev_dy * dw * c;
+            for (int i = 0; i < dw * c; i++)
+                D[i] = vao_sat_u8i((int)nearbyintf(sum[i]));
+        }
+        free(xt); free(yt); free(buf); free(sum);
+        return 0;
+    }
+    /* LINEAR / CUBIC (and AREA when growing = LINEAR with area-style positions) */
+    const int area_mode = mode == 3;
+    if (area_mode) mode = 1;
+    const int ksize = mode == 1 ? 2 : 4, ksize2 = ksize / 2;
+    int *xofs = (int *)malloc(sizeof(int) * (size_t)dw), *yofs = (int *)malloc(sizeof(int) * (size_t)dh);
+    short *ialpha = (short *)malloc(sizeof(short) * (size_t)dw * ksize), *ibeta = (short *)malloc(sizeof(short) * (size_t)dh * ksize);
+    int xmin = 0, xmax = dw;
+    float cbuf[4];
+    for (int dx = 0; dx < dw; dx++) {
+        float fx;
+        int sx;
+        if (!area_mode) {
+            fx = (float)((dx + 0.5) * scale_x - 0.5);
+            sx = (int)floorf(fx);
+            fx -= sx;
+        } else {
+            sx = (int)floor(dx * scale_x);
+            fx = (float)((dx + 1) - (sx + 1) * inv_sx);
+            fx = fx <= 0 ? 0.f : fx - floorf(fx);
+        }
+        if (sx < ksize2 - 1) {
+            xmin = dx + 1;
+            if (sx < 0 && mode == 1) fx = 0, sx = 0;
+        }
+        if (sx + ksize2 >= sw) {
+            if (dx < xmax) xmax = dx;
+            if (sx >= sw - 1 && mode == 1) fx = 0, sx = sw - 1;
+        }
+        xofs[dx] = sx;
+        if (mode == 1) cbuf[0] = 1.f - fx, cbuf[1] = fx;
+        else vao_cubic_coeffs(fx, cbuf);
+        for (int k = 0; k < ksize; k++)
+            ialpha[dx * ksize + k] = vao_sat_short(cbuf[k] * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy;
+        int sy;
+        if (!area_mode) {
+            fy = (float)((dy + 0.5) * scale_y - 0.5);
+            sy = (int)floorf(fy);
+            fy -= sy;
+        } else {
+            sy = (int)floor(dy * scale_y);
+            fy = (float)((dy + 1) - (sy + 1) * inv_sy);
+            fy = fy <= 0 ? 0.f : fy - floorf(fy);
+        }
+        yofs[dy] = sy;
+        if (mode == 1) cbuf[0] = 1.f - fy, cbuf[1] = fy;
+        else vao_cubic_coeffs(fy, cbuf);
+        for (int k = 0; k < ksize; k++)
+            ibeta[dy * ksize + k] = vao_sat_short(cbuf[k] * 2048);
+    }
+    (void)xmin;
+    for (int f = 0; f < n; f++)
+        for (int dy = 0; dy < dh; dy++)
+            for (int dx = 0; dx < dw; dx++)
+                for (int ch = 0; ch < c; ch++) {
+                    int rows[4];
+                    for (int k = 0; k < ksize; k++) {
+                        int sy = yofs[dy] - ksize2 + 1 + k;
+                        sy = sy < 0 ? 0 : sy > sh - 1 ? sh - 1 : sy;
+                        const uint8_t *S = src + f * sfs + (size_t)sy * sw * c;
+                        int v = 0;
+                        if (mode == 1) {
+                            if (dx < xmax)
+                                v = S[xofs[dx] * c + ch] * ialpha[dx * 2] + S[(xofs[dx] + 1) * c + ch] * ialpha[dx * 2 + 1];
+                            else
+                                v = S[xofs[dx] * c + ch] * 2048;
+                        } else {
+                            for (int j = 0; j < 4; j++) {
+                                int sxj = xofs[dx] - 1 + j;
+                                sxj = sxj < 0 ? 0 : sxj > sw - 1 ? sw - 1 : sxj;
+                                v += S[sxj * c + ch] * ialpha[dx * 4 + j];
+                            }
+                        }
+                        rows[k] = v;
+                    }
+                    int out;
+                    if (mode == 1) {
+                        const int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+                        out = (((b0 * (rows[0] >> 4)) >> 16) + ((b1 * (rows[1] >> 4)) >> 16) + 2) >> 2;
+                    } else {
+                        long long s = 0;
+                        for (int k = 0; k < 4; k++)
+                            s += (long long)ibeta[dy * 4 + k] * rows[k];
+                        out = (int)((s + (1 << 21)) >> 22);
+                    }
+                    dst[f * dfs + ((size_t)dy * dw + dx) * c + ch] = vao_sat_u8i(out);
+                }
+    free(xofs); free(yofs); free(ialpha); free(ibeta);
+    (void)vao_round_half_even;
+    return 0;
+}

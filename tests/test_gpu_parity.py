@@ -984,3 +984,44 @@ def test_contracted_chain_speed_1080p():
           "uncontracted %.3f s per 256 frames" % (t_fused, t_chain, t_plain * 8))
     assert a == b
     assert t_chain < 1.5 * t_fused + 0.05
+
+
+@pytest.mark.parametrize("mode", ["nearest", "linear", "cubic", "area"])
+def test_resize_matches_oracle(ops, oracle, mode):
+    """N4 FilterResize / cv2.resize restatement: every mode, shrinking and growing, integer and
+    fractional factors, 1 and 3 channels, batches -- bit for bit against the oracle"""
+    rng = np.random.default_rng(len(mode))
+    img = rng.integers(0, 256, (2, 90, 120), dtype=np.uint8)
+    col = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    img[0, :10] = 255
+    img[1, :, -7:] = 0
+    for size in ((60, 45), (40, 30), (30, 18), (240, 180), (77, 51), (121, 91), (119, 90), (7, 5), (1, 1), (300, 31)):
+        assert np.array_equal(ops.resize(img, size, mode), oracle.resize_u8(img, size, mode)), (mode, size)
+        assert np.array_equal(ops.resize(col, size, mode, color=True),
+                              oracle.resize_u8(col, size, mode, layout="hwc")), (mode, size, "color")
+    big = rng.integers(0, 256, (1, 1080, 1920), dtype=np.uint8)
+    for size in ((960, 540), (640, 360), (1280, 720), (2560, 1440)):
+        assert np.array_equal(ops.resize(big, size, mode), oracle.resize_u8(big, size, mode)), (mode, size)
+    flat = np.full((33, 47), 201, np.uint8)                          # unity gain in every mode
+    assert np.array_equal(ops.resize(flat, (80, 21), mode), np.full((21, 80), 201, np.uint8))
+
+
+def test_filter_resize_plumbing(ops, oracle):
+    from video.filters import FilterResize
+    from video.io.memory import VideoMemory
+    clip = _blob_clip(5, 60, 90, seed=8)
+    src = VideoMemory(clip)
+    half = FilterResize(src, 0.5)                                    # 'auto' on a shrink: area
+    assert half.size == (45, 30) and half.interpolation == "area"
+    assert np.array_equal(np.stack(list(half)), oracle.resize_u8(clip, (45, 30), "area"))
+    up = FilterResize(src, (135, 90))                                # 'auto' on a growth: cubic
+    assert up.interpolation == "cubic" and np.array_equal(up[2], oracle.resize_u8(clip[2], (135, 90), "cubic"))
+    same = FilterResize(src, 1)
+    assert same.interpolation is None and np.array_equal(same[1], clip[1])
+    twice = FilterResize(FilterResize(src, 0.5), (31, 21), "linear", even_dimensions=True)
+    assert twice._source is src and twice.size == (32, 22)           # contracted; even dimensions
+    assert np.array_equal(twice[0], oracle.resize_u8(clip[0], (32, 22), "linear"))
+    with pytest.raises(ValueError):
+        FilterResize(src, 0.5, "bogus")
+    with pytest.raises(NotImplementedError):
+        FilterResize(src, 0.5, "lanczos")

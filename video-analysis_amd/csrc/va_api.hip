@@ -705,6 +705,25 @@ int va_largest_contour(const uint8_t *mask, int n, int h, int w, int32_t *points
     return launch_largest_contour(bits, forest, n, h, w, keys, points, max_points, npoints, area, st);
 }
 
+int va_resize_u8(const uint8_t *src, uint8_t *dst, int n, int src_h, int src_w, int c, int dst_h, int dst_w,
+                 int interpolation, void *stream)
+{
+    VA_ENTER();
+    VA_REQUIRE(src && dst && src != dst, "va_resize_u8: src/dst must be distinct non-NULL");
+    VA_REQUIRE(n >= 0 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0 && c >= 1 && c <= 4,
+               "va_resize_u8: bad shape (%d,%d,%d,%d) -> (%d,%d)", n, src_h, src_w, c, dst_h, dst_w);
+    VA_REQUIRE((size_t)src_h * src_w < kMaxFramePixels && (size_t)dst_h * dst_w < kMaxFramePixels,
+               "va_resize_u8: frames above 2^29 pixels are not supported");
+    VA_REQUIRE(interpolation >= VA_INTER_NEAREST && interpolation <= VA_INTER_AREA,
+               "va_resize_u8: interpolation %d not supported (0 nearest, 1 linear, 2 cubic, 3 area)", interpolation);
+    ScratchLease scratch;
+    int rc = scratch.acquire(resize_scratch_bytes(src_h, src_w, dst_h, dst_w), as_stream(stream));
+    if (rc)
+        return rc;
+    return launch_resize_u8(src, dst, n, src_h, src_w, c, dst_h, dst_w, interpolation, scratch.ptr,
+                            as_stream(stream));
+}
+
 int va_contour_moments(const void *points, const int32_t *npoints, int n, int max_points,
                        int is_float, double *moments_out, void *stream)
 {

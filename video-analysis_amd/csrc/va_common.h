@@ -193,6 +193,10 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
 int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, int h, int w,
                            unsigned long long *best_keys, int32_t *points, int max_points,
                            int32_t *npoints, double *area, hipStream_t st);
+// cv2.resize for uint8 frames (va_resize.hip); mode 0 nearest, 1 linear, 2 cubic, 3 area
+size_t resize_scratch_bytes(int sh, int sw, int dh, int dw);
+int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,
+                     void *scratch, hipStream_t st);
 // cv2.moments(contour): ten spatial moments (float64) per contour, points int32 or float32 (x, y)
 int launch_contour_moments(const void *points, const int32_t *npoints, int n, int max_points,
                            int is_float, double *out, hipStream_t st);

@@ -1,0 +1,341 @@
+// va_resize.hip -- N4: cv2.resize for uint8 frames
+//
+// replaces  cv2.resize(frame, self.size, interpolation=self.interpolation),
+//           FilterResize._process_frame, video/filters.py:310-314 (mode choice :274-293)
+//
+// OpenCV's 8-bit resize is a table-driven algorithm: per output column / row an index and a few
+// fixed-point (11-bit) or float weights, then integer arithmetic with fixed rounding steps.  The
+// tables (a few KB) are built on the host exactly as OpenCV builds them -- same float / double
+// expressions, same saturating conversions -- and the per-pixel arithmetic runs on the GPU, one
+// thread per output sample.  The op is a gather with 1-16 taps per sample: bound by the read of
+// the source frames (L2-friendly: neighbouring outputs share taps) and the write of the result.
+//   mode 0 NEAREST  1 LINEAR (an exact 2x2 shrink is AREA, as in OpenCV)  2 CUBIC (A = -0.75)
+//   mode 3 AREA: integer shrink factors = block means, other shrinks = cell-overlap weights in
+//          float (summation order of OpenCV's ResizeArea_Invoker), growing = LINEAR with
+//          area-style sample positions
+// Parity with real OpenCV is unpinned offline (no cv2); the oracle restates the same published
+// algorithm independently in C (the test-side CPU restatement) and the two are compared bit
+// for bit by the GPU parity tests.
+#include <math.h>
+
+#include <vector>
+
+#include "va_common.h"
+
+namespace va {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ void __launch_bounds__(kBlock)
+resize_nn_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int *__restrict__ xofs,
+                 const int *__restrict__ yofs, int sh, int sw, int c, int dh, int dw, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total)
+        return;
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
+    const size_t f = p / ((size_t)dw * dh);
+    dst[i] = src[(f * sh + yofs[dy]) * (size_t)sw * c + (size_t)xofs[dx] * c + ch];
+}
+
+template <int KS>
+__global__ void __launch_bounds__(kBlock)
+resize_taps_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int *__restrict__ xofs,
+                   const short *__restrict__ ialpha, const int *__restrict__ yofs,
+                   const short *__restrict__ ibeta, int xmax, int sh, int sw, int c, int dh, int dw,
+                   size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total)
+        return;
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
+    const size_t f = p / ((size_t)dw * dh);
+    const uint8_t *frame = src + f * (size_t)sh * sw * c;
+    const int sx = xofs[dx];
+    int rows[KS];
+#pragma unroll
+    for (int k = 0; k < KS; k++) {
+        int sy = yofs[dy] - KS / 2 + 1 + k;
+        sy = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        const uint8_t *S = frame + (size_t)sy * sw * c + ch;
+        int v = 0;
+        if (KS == 2) {
+            if (dx < xmax)
+                v = S[(size_t)sx * c] * ialpha[dx * 2] + S[(size_t)(sx + 1) * c] * ialpha[dx * 2 + 1];
+            else
+                v = S[(size_t)sx * c] * 2048;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int sxj = sx - 1 + j;
+                sxj = sxj < 0 ? 0 : (sxj > sw - 1 ? sw - 1 : sxj);     // replicated border
+                v += S[(size_t)sxj * c] * ialpha[dx * 4 + j];
+            }
+        }
+        rows[k] = v;
+    }
+    int out;
+    if (KS == 2) {
+        const int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+        out = (((b0 * (rows[0] >> 4)) >> 16) + ((b1 * (rows[1] >> 4)) >> 16) + 2) >> 2;
+    } else {
+        long long s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            s += (long long)ibeta[dy * 4 + k] * rows[k];
+        out = (int)((s + (1 << 21)) >> 22);
+    }
+    dst[i] = sat_u8(out);
+}
+
+__global__ void __launch_bounds__(kBlock)
+resize_area_fast_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int isx, int isy,
+                        int wfull, int sh, int sw, int c, int dh, int dw, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total)
+        return;
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
+    const size_t f = p / ((size_t)dw * dh);
+    const uint8_t *frame = src + f * (size_t)sh * sw * c + ch;
+    const int sx0 = dx * isx, sy0 = dy * isy;
+    int sum = 0, count = 0;
+    for (int yy = 0; yy < isy && sy0 + yy < sh; yy++)
+        for (int xx = 0; xx < isx && sx0 + xx < sw; xx++) {
+            sum += frame[((size_t)(sy0 + yy) * sw + sx0 + xx) * c];
+            count++;
+        }
+    int out;
+    if (sy0 + isy <= sh && dx < wfull) {
+        if (isx == 2 && isy == 2)
+            out = (sum + 2) >> 2;
+        else
+            out = __float2int_rn((float)sum * (1.f / (float)(isx * isy)));
+    } else {
+        out = __float2int_rn((float)sum / (float)count);
+    }
+    dst[i] = sat_u8(out);
+}
+
+struct DecAlpha {
+    int si, di;
+    float alpha;
+};
+
+__global__ void __launch_bounds__(kBlock)
+resize_area_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const DecAlpha *__restrict__ xtab,
+                   const int *__restrict__ xstart, const DecAlpha *__restrict__ ytab,
+                   const int *__restrict__ ystart, int sh, int sw, int c, int dh, int dw, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total)
+        return;
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
+    const size_t f = p / ((size_t)dw * dh);
+    const uint8_t *frame = src + f * (size_t)sh * sw * c + ch;
+    float sum = 0.f;
+    bool firstrow = true;
+    for (int j = ystart[dy]; j < ystart[dy + 1]; j++) {
+        const uint8_t *S = frame + (size_t)ytab[j].si * sw * c;
+        float buf = 0.f;
+        for (int k = xstart[dx]; k < xstart[dx + 1]; k++) {
+            const float prod = (float)S[(size_t)xtab[k].si * c] * xtab[k].alpha;
+            buf += prod;
+        }
+        const float t = ytab[j].alpha * buf;
+        sum = firstrow ? t : sum + t;
+        firstrow = false;
+    }
+    dst[i] = sat_u8(__float2int_rn(sum));
+}
+
+short sat_short(float v)
+{
+    const long r = lrintf(v);
+    return (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+
+void cubic_coeffs(float x, float *cf)
+{
+    const float A = -0.75f;
+    cf[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    cf[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    cf[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    cf[3] = 1.f - cf[0] - cf[1] - cf[2];
+}
+
+void area_tab(int ssize, int dsize, double scale, std::vector<DecAlpha> &tab, std::vector<int> &start)
+{
+    start.assign(dsize + 1, 0);
+    for (int dx = 0; dx < dsize; dx++) {
+        start[dx] = (int)tab.size();
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = fmin(scale, ssize - fsx1);
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+        sx1 = sx1 < sx2 ? sx1 : sx2;
+        if (sx1 - fsx1 > 1e-3)
+            tab.push_back({sx1 - 1, dx, (float)((sx1 - fsx1) / cell)});
+        for (int sx = sx1; sx < sx2; sx++)
+            tab.push_back({sx, dx, (float)(1.0 / cell)});
+        if (fsx2 - sx2 > 1e-3)
+            tab.push_back({sx2, dx, (float)(fmin(fmin(fsx2 - sx2, 1.), cell) / cell)});
+    }
+    start[dsize] = (int)tab.size();
+}
+
+// index / weight tables of the LINEAR and CUBIC paths along one axis
+void taps_tab(int ssize, int dsize, int ksize, bool area_mode, bool clamp_linear, std::vector<int> &ofs,
+              std::vector<short> &coef, int *xmax_out)
+{
+    const double inv = (double)dsize / ssize, scale = 1. / inv;
+    const int ksize2 = ksize / 2;
+    ofs.resize(dsize);
+    coef.resize((size_t)dsize * ksize);
+    int xmax = dsize;
+    float cbuf[4];
+    for (int d = 0; d < dsize; d++) {
+        float fx;
+        int sx;
+        if (!area_mode) {
+            fx = (float)((d + 0.5) * scale - 0.5);
+            sx = (int)floorf(fx);
+            fx -= sx;
+        } else {
+            sx = (int)floor(d * scale);
+            fx = (float)((d + 1) - (sx + 1) * inv);
+            fx = fx <= 0 ? 0.f : fx - floorf(fx);
+        }
+        if (clamp_linear) {        // the x axis: positions are clamped in the table (rows are clipped on use)
+            if (sx < ksize2 - 1 && sx < 0 && ksize == 2)
+                fx = 0, sx = 0;
+            if (sx + ksize2 >= ssize) {
+                xmax = d < xmax ? d : xmax;
+                if (sx >= ssize - 1 && ksize == 2)
+                    fx = 0, sx = ssize - 1;
+            }
+        }
+        ofs[d] = sx;
+        if (ksize == 2)
+            cbuf[0] = 1.f - fx, cbuf[1] = fx;
+        else
+            cubic_coeffs(fx, cbuf);
+        for (int k = 0; k < ksize; k++)
+            coef[(size_t)d * ksize + k] = sat_short(cbuf[k] * 2048);
+    }
+    if (xmax_out)
+        *xmax_out = xmax;
+}
+
+}  // namespace
+
+// scratch_bytes: size of the device buffer launch_resize_u8 needs for its tables
+size_t resize_scratch_bytes(int sh, int sw, int dh, int dw)
+{
+    const size_t ints = (size_t)dw + dh + 4 + (size_t)dw + dh + 4;
+    const size_t shorts = 4 * ((size_t)dw + dh);
+    const size_t tabs = 2 * ((size_t)sw + sh) + 2 * ((size_t)dw + dh) + 8;
+    return ints * 4 + shorts * 2 + tabs * sizeof(DecAlpha) + 1024;
+}
+
+int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,
+                     void *scratch, hipStream_t st)
+{
+    VA_REQUIRE(src && dst && scratch, "resize: NULL argument");
+    VA_REQUIRE(n >= 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && c > 0 && c <= 4, "resize: bad shape");
+    VA_REQUIRE(mode >= 0 && mode <= 3, "resize: interpolation must be 0 nearest, 1 linear, 2 cubic or 3 area");
+    const size_t total = (size_t)n * dh * dw * c;
+    if (total == 0)
+        return VA_OK;
+    const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+    const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+    const unsigned grid = (unsigned)cdiv((long long)total, kBlock);
+    char *base = (char *)scratch;
+    size_t used = 0;
+    auto push = [&](const void *host, size_t bytes, void **dev) -> int {
+        used = (used + 15) & ~(size_t)15;
+        *dev = base + used;
+        // (pageable source: the runtime stages the bytes before hipMemcpyAsync returns)
+        VA_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, st));
+        used += bytes;
+        return VA_OK;
+    };
+    int rc;
+    if (mode == 0) {
+        std::vector<int> xo(dw), yo(dh);
+        const double ifx = 1. / inv_sx, ify = 1. / inv_sy;
+        for (int x = 0; x < dw; x++) {
+            const int sx = (int)floor(x * ifx);
+            xo[x] = sx < sw - 1 ? sx : sw - 1;
+        }
+        for (int y = 0; y < dh; y++) {
+            const int sy = (int)floor(y * ify);
+            yo[y] = sy < sh - 1 ? sy : sh - 1;
+        }
+        void *dx, *dy;
+        if ((rc = push(xo.data(), xo.size() * 4, &dx)) || (rc = push(yo.data(), yo.size() * 4, &dy)))
+            return rc;
+        resize_nn_kernel<<<grid, kBlock, 0, st>>>(src, dst, (const int *)dx, (const int *)dy, sh, sw, c, dh, dw, total);
+        VA_LAUNCH_CHECK("resize_nn_kernel");
+        return VA_OK;
+    }
+    const int iscale_x = (int)nearbyint(scale_x), iscale_y = (int)nearbyint(scale_y);
+    const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 &&
+                           fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    if (mode == 1 && area_fast && iscale_x == 2 && iscale_y == 2)
+        mode = 3;
+    if (mode == 3 && scale_x >= 1 && scale_y >= 1) {
+        if (area_fast) {
+            int wfull = (int)(sw / scale_x);
+            wfull = wfull < dw ? wfull : dw;
+            resize_area_fast_kernel<<<grid, kBlock, 0, st>>>(src, dst, iscale_x, iscale_y, wfull, sh, sw, c, dh,
+                                                            dw, total);
+            VA_LAUNCH_CHECK("resize_area_fast_kernel");
+            return VA_OK;
+        }
+        std::vector<DecAlpha> xt, yt;
+        std::vector<int> xs, ys;
+        area_tab(sw, dw, scale_x, xt, xs);
+        area_tab(sh, dh, scale_y, yt, ys);
+        void *dxt, *dxs, *dyt, *dys;
+        if ((rc = push(xt.data(), xt.size() * sizeof(DecAlpha), &dxt)) || (rc = push(xs.data(), xs.size() * 4, &dxs)) ||
+            (rc = push(yt.data(), yt.size() * sizeof(DecAlpha), &dyt)) || (rc = push(ys.data(), ys.size() * 4, &dys)))
+            return rc;
+        resize_area_kernel<<<grid, kBlock, 0, st>>>(src, dst, (const DecAlpha *)dxt, (const int *)dxs,
+                                                   (const DecAlpha *)dyt, (const int *)dys, sh, sw, c, dh, dw, total);
+        VA_LAUNCH_CHECK("resize_area_kernel");
+        return VA_OK;
+    }
+    const bool area_mode = mode == 3;
+    const int ksize = (mode == 2) ? 4 : 2;
+    std::vector<int> xo, yo;
+    std::vector<short> ia, ib;
+    int xmax = dw;
+    taps_tab(sw, dw, ksize, area_mode, true, xo, ia, &xmax);
+    taps_tab(sh, dh, ksize, area_mode, false, yo, ib, nullptr);
+    void *dxo, *dia, *dyo, *dib;
+    if ((rc = push(xo.data(), xo.size() * 4, &dxo)) || (rc = push(ia.data(), ia.size() * 2, &dia)) ||
+        (rc = push(yo.data(), yo.size() * 4, &dyo)) || (rc = push(ib.data(), ib.size() * 2, &dib)))
+        return rc;
+    if (ksize == 2)
+        resize_taps_kernel<2><<<grid, kBlock, 0, st>>>(src, dst, (const int *)dxo, (const short *)dia, (const int *)dyo,
+                                                      (const short *)dib, xmax, sh, sw, c, dh, dw, total);
+    else
+        resize_taps_kernel<4><<<grid, kBlock, 0, st>>>(src, dst, (const int *)dxo, (const short *)dia, (const int *)dyo,
+                                                      (const short *)dib, xmax, sh, sw, c, dh, dw, total);
+    VA_LAUNCH_CHECK("resize_taps_kernel");
+    return VA_OK;
+}
+
+}  // namespace va

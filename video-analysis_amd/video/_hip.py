@@ -98,6 +98,7 @@ SIGNATURES = {
     "va_image_statistics_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp]),
     "va_contour_workspace_bytes": (_sz, [_i, _i, _i]),
     "va_largest_contour": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "va_resize_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "va_contour_moments": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "va_pipeline_create": (_i, [C.POINTER(va_config), C.POINTER(_vp)]),
     "va_pipeline_destroy": (_i, [_vp]),

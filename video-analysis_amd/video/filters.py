@@ -1,7 +1,7 @@
 """video.filters -- lazy per-frame filters whose pixel work runs on the MI355X.
 
 API surface of the reference's video/filters.py (FilterFunction :56, FilterNormalize :76,
-FilterCrop :158, FilterMonochrome :348, FilterBlur :378, FilterDiffBase :492,
+FilterCrop :158, FilterResize :252, FilterMonochrome :348, FilterBlur :378, FilterDiffBase :492,
 FilterTimeDifference :542) plus the BUILD-DEFINED classes the north star names but the
 reference does not contain: FilterBackground, FilterThreshold, FilterMorphology,
 and FilterAnalysisChain, the batched fused form of the whole chain.
@@ -136,6 +136,47 @@ class FilterCrop(VideoFilterBase):
         else:
             frame = frame[self.slices[0], self.slices[1], self.color_channel]
         return super(FilterCrop, self)._process_frame(frame)
+
+
+class FilterResize(VideoFilterBase):
+    """resizes the video to `size` = (width, height), or by a factor if `size` is a number
+    (reference :252-315: cv2.resize).  `interpolation`: 'auto' (area when the frame shrinks, cubic
+    when it grows), 'nearest', 'linear', 'area', 'cubic'; 'lanczos' is not provided on the GPU.
+    Consecutive resizes contract into one (:299-301).  uint8 frames."""
+
+    def __init__(self, source, size=None, interpolation="auto", even_dimensions=False):
+        if hasattr(size, "__iter__"):
+            width, height = size
+        else:
+            width = int(source.size[0] * size)
+            height = int(source.size[1] * size)
+        if even_dimensions:
+            width += width % 2
+            height += height % 2
+        if (width, height) == tuple(source.size):
+            self.interpolation = None
+        elif interpolation == "auto":
+            shrinks = width * height < source.size[0] * source.size[1]
+            self.interpolation = "area" if shrinks else "cubic"
+        elif interpolation in ("nearest", "linear", "area", "cubic"):
+            self.interpolation = interpolation
+        elif interpolation == "lanczos":
+            raise NotImplementedError("FilterResize: INTER_LANCZOS4 is not provided on the GPU path")
+        else:
+            raise ValueError("Unknown interpolation method: %s" % (interpolation,))
+        while isinstance(source, FilterResize):        # contract with parent resize filters
+            logger.debug("Combine this resize filter with the parent one.")
+            source = source._source
+        super(FilterResize, self).__init__(source, size=(width, height))
+        logger.debug("Created filter for resizing to size %dx%d", width, height)
+
+    def _process_frame(self, frame):
+        if self.interpolation:
+            frame = np.asarray(frame)
+            if frame.dtype != np.uint8:
+                raise TypeError("FilterResize: only uint8 frames are supported on the GPU path")
+            frame = ops.resize(frame, self.size, self.interpolation, color=frame.ndim == 3)
+        return super(FilterResize, self)._process_frame(frame)
 
 
 class FilterMonochrome(VideoFilterBase):

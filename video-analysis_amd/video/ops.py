@@ -241,6 +241,33 @@ def normalize(frames, fmin, fmax, alpha, tmin):
                          float(alpha), float(tmin), None)
 
 
+INTERPOLATIONS = {"nearest": 0, "linear": 1, "cubic": 2, "area": 3}
+
+
+def resize(frames, size, interpolation="linear", color=False):
+    """cv2.resize(frame, size, interpolation=...) per frame (FilterResize, video/filters.py:310-314);
+    size = (width, height); uint8 frames (H,W) / (N,H,W), with color=True (H,W,C) / (N,H,W,C)"""
+    frames = np.asarray(frames)
+    if frames.dtype != np.uint8:
+        raise TypeError("resize supports uint8 frames on the GPU path, got %s" % frames.dtype)
+    if interpolation not in INTERPOLATIONS:
+        raise ValueError("Unknown interpolation method: %s" % (interpolation,))
+    arr, n, fshape, single = _as_batch(frames, 3 if color else 2)
+    h, w, c = _hwc(fshape)
+    dw, dh = int(size[0]), int(size[1])
+    if dw < 1 or dh < 1:
+        raise ValueError("target size must be positive, got %r" % (size,))
+    out_shape = (n, dh, dw) + ((c,) if color else ())
+    src = _upload(arr)
+    dst = _take(int(np.prod(out_shape)))
+    try:
+        check(_hip.lib().va_resize_u8(src.ptr, dst.ptr, n, h, w, c, dh, dw, INTERPOLATIONS[interpolation], None))
+        out = dst.download(out_shape, np.uint8)
+    finally:
+        _give(src, dst)
+    return out[0] if single else out
+
+
 def morph(frames, op, shape="rect", ksize=3, implementation=None):
     """cv2.erode / cv2.dilate (video/analysis/image.py:248-251) on (H,W) or (N,H,W) uint8.
     implementation='bits' runs the bit-packed kernel of the pipeline (binary masks only)."""
