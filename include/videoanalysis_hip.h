@@ -50,6 +50,7 @@ extern "C" {
 /* dtypes */
 #define VA_U8 0
 #define VA_F32 1
+#define VA_F64 2 /* targets of va_normalize / va_gaussian_noise only */
 /* background modes (BUILD-DEFINED FilterBackground; arithmetic of video/analysis/video.py) */
 #define VA_BG_NONE 0
 #define VA_BG_MEAN 1   /* cumulative mean, float64 state: measure_mean, video/analysis/video.py:33 */
@@ -138,6 +139,18 @@ int va_mono_mean_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t pixels, voi
  *           clip to [fmin,fmax]; (f - fmin)*alpha + tmin in float64; astype(uint8) */
 int va_normalize_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t count, double fmin,
                     double fmax, double alpha, double tmin, void *stream);
+/* the same for float32 or uint8 frames and uint8 / float32 / float64 targets (the reference takes
+ * any dtype, video/filters.py:101-135): clip, affine map in float64, C cast to the target */
+int va_normalize(const void *src_dev, int src_dtype, void *dst_dev, int dst_dtype, size_t count,
+                 double fmin, double fmax, double alpha, double tmin, void *stream);
+/* replaces  self.mean + self.std*np.random.randn(*self._frame_shape), VideoGaussianNoise.get_frame,
+ *           video/io/computed.py:36-41, on the device (N4): sample i of the stream is a pure
+ * function of (seed, i) -- Philox4x32-10 counter, Box-Muller in float64 -- so any frame can be
+ * produced on its own: count samples starting at absolute sample index first_index
+ * (= frame_index * samples_per_frame).  dtype VA_U8 (saturated to [0, 255], truncated), VA_F32
+ * or VA_F64.  The reference's stream is unseeded NumPy state: agreement is statistical. */
+int va_gaussian_noise(void *dst_dev, int dtype, size_t count, double mean, double stdev, uint64_t seed,
+                      uint64_t first_index, void *stream);
 /* replaces  np.rot90(frame, angle // 90), FilterRotate._process_frame, video/filters.py:339-344
  * (N4): n frames (h, w) of opaque elem_bytes-byte pixels (channels x dtype: 1, 2, 3, 4, 6, 8 or
  * 12 bytes) turned k quarter turns counter-clockwise; output frames are (w, h) for odd k. */

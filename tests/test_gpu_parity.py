@@ -1025,3 +1025,118 @@ def test_filter_resize_plumbing(ops, oracle):
         FilterResize(src, 0.5, "bogus")
     with pytest.raises(NotImplementedError):
         FilterResize(src, 0.5, "lanczos")
+
+
+def _philox_normals(seed, first_index, count):
+    """NumPy restatement of va_gaussian_noise's stream: Philox4x32-10 on the pair counter, two
+    53-bit uniforms, Box-Muller in float64 (checker only)"""
+    pair0 = first_index >> 1
+    npairs = ((first_index + count + 1) >> 1) - pair0
+    g = (np.arange(npairs, dtype=np.uint64) + np.uint64(pair0))
+    c = [(g & np.uint64(0xFFFFFFFF)), (g >> np.uint64(32)), np.zeros(npairs, np.uint64), np.zeros(npairs, np.uint64)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    M = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & M, p0 & M]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    u1 = ((((c[0] << np.uint64(32)) | c[1]) >> np.uint64(11)).astype(np.float64) + 1.0) / 9007199254740992.0
+    u2 = (((c[2] << np.uint64(32)) | c[3]) >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
+    rad = np.sqrt(-2.0 * np.log(u1))
+    z = np.stack([rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)], 1).ravel()
+    off = first_index - 2 * pair0
+    return z[off:off + count]
+
+
+def test_gaussian_noise_video_on_device(ops):
+    """N4: VideoGaussianNoise frames come from the GPU: reproducible and seekable (sample i is a
+    function of (seed, i)), the documented Philox / Box-Muller stream, right statistics, and
+    straight into device memory for the engine"""
+    from video._hip import DeviceBuffer
+    from video.io.computed import VideoGaussianNoise
+    g = VideoGaussianNoise(6, (50, 31), mean=3.0, std=2.0, seed=11)
+    f2 = g[2]
+    assert f2.dtype == np.float64 and f2.shape == (31, 50)
+    assert np.array_equal(f2, g[2]) and not np.array_equal(g[1], f2)
+    frames = np.stack(list(g))
+    ref = _philox_normals(11, 0, frames.size).reshape(frames.shape) * 2.0 + 3.0
+    assert np.allclose(frames, ref, rtol=0, atol=1e-12)                  # device libm vs NumPy: last bits only
+    assert np.array_equal(frames[2], f2)                                # a frame on its own == inside the sequence
+    odd = ops.gaussian_noise((7,), np.float64, 0.0, 1.0, seed=11, first_index=5)     # unaligned windows of the stream
+    assert np.allclose(odd, _philox_normals(11, 5, 7), atol=1e-12)
+    big = VideoGaussianNoise(2, (640, 480), mean=100, std=10, seed=5, dtype=np.float32)[1]
+    assert abs(big.mean() - 100) < 0.1 and abs(big.std() - 10) < 0.1
+    assert abs(((big - 100) ** 3).mean()) < 30 and abs(((big - 100) / 10) ** 4).mean() - 3 < 0.1
+    u8 = VideoGaussianNoise(3, (64, 48), mean=250, std=20, seed=1, dtype=np.uint8, is_color=True)
+    fr = u8[0]
+    assert fr.dtype == np.uint8 and fr.shape == (48, 64, 3) and fr.max() == 255 and (fr == 255).mean() > 0.3
+    want = np.clip(_philox_normals(1, 0, fr.size) * 20 + 250, 0, 255)
+    assert np.abs(fr.ravel().astype(np.float64) - np.trunc(want)).max() <= 1      # (truncation next to an integer)
+    # generated in place for the engine: no host copy
+    src = VideoGaussianNoise(8, (96, 64), mean=100, std=30, seed=9, dtype=np.uint8)
+    dev = DeviceBuffer(8 * 96 * 64)
+    src.fill_device(dev.ptr, 0, 8)
+    assert np.array_equal(dev.download((8, 64, 96), np.uint8), np.stack(list(src)))
+    dev.free()
+
+
+def test_filter_normalize_other_dtypes(ops):
+    """A5: FilterNormalize for float32 frames / float targets (video/filters.py:101-135)"""
+    from video.filters import FilterNormalize
+    from video.io.memory import VideoMemory
+    rng = np.random.default_rng(4)
+    f32 = (rng.random((4, 30, 40), dtype=np.float32) * 3 - 1).astype(np.float32)
+    v = FilterNormalize(VideoMemory(f32), 0.0, 1.5, dtype=np.uint8)
+    ref = ((np.clip(f32.astype(np.float64), 0.0, 1.5) - 0.0) * (255 / 1.5) + 0).astype(np.int64).astype(np.uint8)
+    assert np.array_equal(np.stack(list(v)), ref)
+    u8 = rng.integers(0, 256, (3, 20, 30), dtype=np.uint8)
+    w = FilterNormalize(VideoMemory(u8), 50, 200, dtype=np.float32)
+    refw = ((np.clip(u8.astype(np.float64), 50, 200) - 50) * (1.0 / 150.0) + 0).astype(np.float32)
+    assert np.array_equal(np.stack(list(w)), refw)
+    auto = FilterNormalize(VideoMemory(f32))                         # limits and dtype learnt from the first frame
+    a0 = auto[0]
+    assert a0.dtype == np.float32 and a0.min() == 0.0 and abs(a0.max() - 1.0) < 1e-6
+    d64 = FilterNormalize(VideoMemory(u8), 0, 255, dtype=np.float64)[1]
+    assert d64.dtype == np.float64 and np.array_equal(d64, u8[1].astype(np.float64) * (1.0 / 255.0))
+
+
+def test_fork_and_analysis_preprocessor_on_gpu(oracle):
+    """N3: VideoFork feeding two GPU filter chains in lock step, and the dict-per-frame
+    VideoAnalysisPreprocessor ({'raw','blur','mask','labels','count','stats'}) on the streamed engine"""
+    from video import filters as F
+    from video.io.base import VideoFork
+    from video.io.memory import VideoMemory
+    from video.io.parallel import VideoAnalysisPreprocessor, VideoPreprocessor
+    clip = _blob_clip(45, 72, 104, seed=21, salt=0.003)
+    rm, rl, rc, _ = oracle.chain_u8(clip, 2.0, 20, morph_ksize=5, connectivity=4)
+    rdiff, _ = oracle.bg_mean_u8(clip)
+    rblur = oracle.gaussian_u8(rdiff, 2.0)
+    fork = VideoFork(VideoMemory(clip))
+    masks = F.FilterMorphology(F.FilterThreshold(F.FilterBlur(F.FilterBackground(fork.get_client()), 2), 20), "close", 5)
+    small = F.FilterResize(fork.get_client(), 0.5)
+    k = 0
+    for m, s in zip(masks, small):                     # NB: the contracted chain prefetches a batch ...
+        assert np.array_equal(m, rm[k]) and np.array_equal(s, oracle.resize_u8(clip[k], (52, 36), "area"))
+        k += 1
+    assert k == 45
+    pre = VideoAnalysisPreprocessor(VideoMemory(clip), outputs=("blur", "mask", "labels", "count", "stats"),
+                                    sigma=2.0, threshold=20, max_labels=32, batch=16)
+    assert len(pre) == 45
+    n = 0
+    for d in pre:
+        assert set(d) == {"raw", "blur", "mask", "labels", "count", "stats"}
+        assert np.array_equal(d["raw"], clip[n]) and np.array_equal(d["blur"], rblur[n])
+        assert np.array_equal(d["mask"], rm[n]) and np.array_equal(d["labels"], rl[n]) and d["count"] == rc[n]
+        c = min(int(rc[n]), 32)
+        assert np.array_equal(d["stats"][:c, :14], oracle.region_stats(rl[n], int(rc[n]))[:c, :14])
+        n += 1
+    assert n == 45
+    # the reference's form with GPU callables in worker threads (ctypes releases the GIL)
+    from video import ops
+    pre2 = VideoPreprocessor(VideoMemory(clip[:12]), {"blur": lambda f: ops.gaussian_blur(f, 2.0),
+                                                     "big": lambda f: ops.threshold(f, 128)})
+    for i, d in enumerate(pre2):
+        assert np.array_equal(d["blur"], oracle.gaussian_u8(clip[i], 2.0))
+        assert np.array_equal(d["big"], oracle.threshold_u8(clip[i], 128))

@@ -201,11 +201,20 @@ def test_stateful_filter_format_and_argument_checks():
         FilterAnalysisChain(vc)
 
 
-def test_gaussian_noise_source_is_repeatable():
-    g = VideoGaussianNoise(5, (16, 8), mean=100, std=10, seed=3)
-    assert g.shape == (5, 8, 16) and g[2].dtype == np.uint8
-    assert np.array_equal(g[2], g[2]) and not np.array_equal(g[1], g[2])
-    assert len(list(g)) == 5
+def test_gaussian_noise_source_format_and_no_cpu_fallback():
+    """VideoGaussianNoise generates its frames on the GPU (va_gaussian_noise); without one there is
+    no host fallback (the repeatability / statistics checks are GPU tests)"""
+    from video import _hip
+    g = VideoGaussianNoise(5, (16, 8), mean=100, std=10, seed=3, dtype=np.uint8)
+    assert g.shape == (5, 8, 16) and g.dtype == np.uint8 and g.seekable and len(g) == 5
+    assert VideoGaussianNoise(2, (4, 4)).dtype == np.float64          # the reference's default
+    with pytest.raises(IndexError):
+        g.get_frame(5)
+    with pytest.raises(TypeError):
+        VideoGaussianNoise(2, (4, 4), dtype=np.int16)
+    if not _hip.gpu_available():
+        with pytest.raises(_hip.HipUnavailableError):
+            g.get_frame(2)
 
 
 def test_replicate_and_drop_frames_are_index_maps():
@@ -222,3 +231,70 @@ def test_replicate_and_drop_frames_are_index_maps():
     assert len(FilterDropFrames(v, 2.5)) == 3 and np.array_equal(FilterDropFrames(v, 2.5)[2], data[5])
     with pytest.raises(ValueError):
         FilterReplicate(v, 0)
+
+
+def test_video_fork_distributes_frames_in_lock_step():
+    """VideoFork (reference: video/io/base.py:516-662): one pull per frame, clients in lock step,
+    SynchronizationError for a client that runs ahead or jumps, SystemExit after an abort"""
+    from video.filters import FilterCrop, FilterFunction
+    from video.io.base import SynchronizationError, VideoFork
+    v, data = _video(6)
+    pulls = []
+    fork = VideoFork(v)
+    fork.register_listener(lambda f: pulls.append(int(f[0, 0])))     # called once per pulled frame
+    a = FilterFunction(fork.get_client(), lambda f: f.astype(np.int32) + 1)
+    b = FilterCrop(fork.get_client(), region="left")
+    assert fork.client_count == 2
+    with pytest.raises(RuntimeError):
+        iter(fork)
+    seen = 0
+    for fa, fb in zip(a, b):
+        assert np.array_equal(fa, data[seen].astype(np.int32) + 1)
+        assert np.array_equal(fb, data[seen][:, :data.shape[2] // 2])
+        seen += 1
+    assert seen == 6 and pulls == [int(d[0, 0]) for d in data]          # every frame read once
+    # a client that runs ahead of the other one
+    fork = VideoFork(_video(4)[0])
+    c1, c2 = fork.get_client(), fork.get_client()
+    c1.get_next_frame()
+    with pytest.raises(SynchronizationError):
+        c1.get_next_frame()
+    c2.get_next_frame()
+    c1.get_next_frame()                                                 # now both have read frame 0
+    with pytest.raises(SynchronizationError):
+        fork.get_frame(3)                                               # neither cached nor next
+    # unsynchronised forks do not count, a fixed client_count limits get_client
+    fork = VideoFork(_video(4)[0], synchronized=False, client_count=1)
+    c = fork.get_client()
+    assert len(list(c)) == 4
+    with pytest.raises(ValueError):
+        fork.get_client()
+    # abort: every other client gets SystemExit
+    fork = VideoFork(_video(4)[0])
+    c1, c2 = fork.get_client(), fork.get_client()
+    c1.get_next_frame()
+    c2.close()
+    with pytest.raises(SystemExit):
+        c1.get_next_frame()
+
+
+def test_video_preprocessor_dict_per_frame():
+    """VideoPreprocessor (reference: video/io/parallel.py:386-488) with host callables"""
+    from video.io.parallel import VideoPreprocessor
+    v, data = _video(9)
+    for use_threads in (True, False):
+        pre = VideoPreprocessor(v, {"double": lambda f: f.astype(np.int32) * 2, "mean": lambda f: float(f.mean())},
+                                preprocess=lambda f: f[::2], use_threads=use_threads)
+        assert len(pre) == 9
+        out = list(pre)
+        assert len(out) == 9
+        for k, d in enumerate(out):
+            assert set(d) == {"raw", "double", "mean"}
+            assert np.array_equal(d["raw"], data[k][::2])
+            assert np.array_equal(d["double"], data[k][::2].astype(np.int32) * 2) and d["mean"] == data[k][::2].mean()
+    with pytest.raises(KeyError):
+        VideoPreprocessor(v, {"raw": lambda f: f})
+    def boom(frame):
+        raise ValueError("worker failed")
+    with pytest.raises(ValueError):
+        list(VideoPreprocessor(v, {"boom": boom}))

@@ -481,6 +481,20 @@ int va_normalize_u8(const uint8_t *src, uint8_t *dst, size_t count, double fmin,
     return launch_normalize_u8(src, dst, count, fmin, fmax, alpha, tmin, as_stream(stream));
 }
 
+int va_normalize(const void *src, int src_dtype, void *dst, int dst_dtype, size_t count, double fmin,
+                 double fmax, double alpha, double tmin, void *stream)
+{
+    VA_ENTER();
+    return launch_normalize(src, src_dtype, dst, dst_dtype, count, fmin, fmax, alpha, tmin, as_stream(stream));
+}
+
+int va_gaussian_noise(void *dst, int dtype, size_t count, double mean, double stdev, uint64_t seed,
+                      uint64_t first_index, void *stream)
+{
+    VA_ENTER();
+    return launch_gaussian_noise(dst, dtype, count, mean, stdev, seed, first_index, as_stream(stream));
+}
+
 int va_rot90(const void *src, void *dst, int n, int h, int w, int elem_bytes, int k, void *stream)
 {
     VA_ENTER();

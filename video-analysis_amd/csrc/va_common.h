@@ -193,6 +193,11 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
 int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, int h, int w,
                            unsigned long long *best_keys, int32_t *points, int max_points,
                            int32_t *npoints, double *area, hipStream_t st);
+// FilterNormalize for uint8 / float32 frames, any of the three target dtypes; seeded noise frames
+int launch_normalize(const void *src, int src_dtype, void *dst, int dst_dtype, size_t count, double fmin,
+                     double fmax, double alpha, double tmin, hipStream_t st);
+int launch_gaussian_noise(void *dst, int dtype, size_t count, double mean, double stdev, uint64_t seed,
+                          uint64_t first_index, hipStream_t st);
 // cv2.resize for uint8 frames (va_resize.hip); mode 0 nearest, 1 linear, 2 cubic, 3 area
 size_t resize_scratch_bytes(int sh, int sw, int dh, int dw);
 int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,

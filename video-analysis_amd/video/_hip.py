@@ -12,7 +12,7 @@ import numpy as np
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_DIR, "lib", "libvideoanalysis_hip.so")
 
-VA_U8, VA_F32 = 0, 1
+VA_U8, VA_F32, VA_F64 = 0, 1, 2
 BG_NONE, BG_MEAN, BG_EMA, BG_STATIC = 0, 1, 2, 3
 MORPH_ERODE, MORPH_DILATE = 0, 1
 SHAPE_RECT, SHAPE_CROSS, SHAPE_ELLIPSE = 0, 1, 2
@@ -98,6 +98,8 @@ SIGNATURES = {
     "va_image_statistics_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp]),
     "va_contour_workspace_bytes": (_sz, [_i, _i, _i]),
     "va_largest_contour": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "va_normalize": (_i, [_vp, _i, _vp, _i, _sz, _d, _d, _d, _d, _vp]),
+    "va_gaussian_noise": (_i, [_vp, _i, _sz, _d, _d, C.c_uint64, C.c_uint64, _vp]),
     "va_resize_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "va_contour_moments": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "va_pipeline_create": (_i, [C.POINTER(va_config), C.POINTER(_vp)]),

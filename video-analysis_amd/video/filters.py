@@ -51,7 +51,9 @@ class FilterFunction(VideoFilterBase):
 
 class FilterNormalize(VideoFilterBase):
     """maps the colour interval [vmin, vmax] onto the full range of `dtype`
-    (reference :76-135): clip, (f - fmin)*alpha + tmin, astype.  uint8 -> uint8 on the GPU."""
+    (reference :76-135): clip, (f - fmin)*alpha + tmin, astype.  uint8 and float32 frames,
+    uint8 / float32 / float64 targets, on the GPU.  (The reference clips the SOURCE frame in
+    place, `np.clip(..., out=frame)`; the source's frames are left untouched here.)"""
 
     def __init__(self, source, vmin=None, vmax=None, dtype=None):
         self._fmin, self._fmax = vmin, vmax
@@ -61,12 +63,12 @@ class FilterNormalize(VideoFilterBase):
 
     def _process_frame(self, frame):
         frame = np.asarray(frame)
-        if frame.dtype != np.uint8:
-            raise TypeError("FilterNormalize: only uint8 frames are supported on the GPU path")
+        if frame.dtype not in (np.uint8, np.float32):
+            raise TypeError("FilterNormalize: uint8 and float32 frames are supported on the GPU path")
         if self._dtype is None:                 # learnt lazily from the first frame (:104-109)
             self._dtype = frame.dtype
-        if self._dtype != np.uint8:
-            raise TypeError("FilterNormalize: only dtype=uint8 targets are supported")
+        if self._dtype not in (np.uint8, np.float32, np.float64):
+            raise TypeError("FilterNormalize: targets are uint8, float32 or float64")
         if self._fmin is None:
             self._fmin = frame.min()
         if self._fmax is None:
@@ -74,7 +76,10 @@ class FilterNormalize(VideoFilterBase):
         if self._tmin is None:
             self._tmin, tmax = get_color_range(self._dtype)
             self._alpha = (tmax - self._tmin) / (float(self._fmax) - float(self._fmin))
-        out = ops.normalize(frame, self._fmin, self._fmax, self._alpha, self._tmin)
+        if frame.dtype == np.uint8 and self._dtype == np.uint8:
+            out = ops.normalize(frame, self._fmin, self._fmax, self._alpha, self._tmin)
+        else:
+            out = ops.normalize_any(frame, self._fmin, self._fmax, self._alpha, self._tmin, self._dtype)
         return super(FilterNormalize, self)._process_frame(out)
 
 
@@ -228,8 +233,8 @@ class _GpuStage(object):
             node = node._source
         stages.reverse()
         root = node
-        if not self.contract or len(stages) < 2 or root.is_color:
-            return None
+        if not self.contract or len(stages) < 2 or root.is_color or not root.seekable:
+            return None         # (batched prefetch needs random access: fork clients, pipes stay per-frame)
         order = {"background": 0, "blur": 1, "threshold": 2, "morphology": 3}
         kinds = [st._stage()[0] for st in stages]
         ranks = [order[k] for k in kinds]

@@ -5,6 +5,6 @@ arrays are ``(frames, height, width[, 3])``; frames are NumPy arrays and sources
 views of their storage, so consumers copy what they keep.
 """
 from .base import (NotSeekableError, SynchronizationError, VideoBase, VideoFilterBase,  # noqa
-                   VideoIterator, VideoSlice)
+                   VideoFork, VideoIterator, VideoSlice)
 from .memory import VideoMemory  # noqa
 from .computed import VideoGaussianNoise  # noqa

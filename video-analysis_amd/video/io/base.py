@@ -280,3 +280,114 @@ class VideoSlice(VideoFilterBase):
             frame = self._source.get_frame(self._start + self._frame_pos * self._step)
         self._frame_pos += 1
         return self._process_frame(frame)
+
+
+class _VideoForkClient(VideoBase):
+    """one consumer of a VideoFork: iterating it asks the fork for frame `_frame_pos`
+    (reference: video/io/base.py:478-513)"""
+
+    def __init__(self, video_fork):
+        self._parent = video_fork
+        super(_VideoForkClient, self).__init__(**video_fork.video_format)
+
+    def get_next_frame(self):
+        frame = self._parent.get_frame(self._frame_pos)
+        self._frame_pos += 1
+        if frame is StopIteration:
+            raise StopIteration
+        return frame
+
+    def set_frame_pos(self, index):
+        self._frame_pos = index + self.frame_count if index < 0 else index
+
+    def abort_iteration(self):
+        self._parent.abort_iteration()
+        super(_VideoForkClient, self).abort_iteration()
+
+    def close(self):
+        """asks the fork to send SystemExit to all clients"""
+        self._parent.abort_iteration()
+
+
+class VideoFork(VideoFilterBase):
+    """hands the frames of one video to several consumers that are iterated in lock step
+    (reference: video/io/base.py:516-662):
+
+        fork = VideoFork(video)
+        a, b = FilterBlur(fork.get_client(), 2), FilterCrop(fork.get_client(), region='left')
+        for frame_a, frame_b in zip(a, b):
+            ...
+
+    Every frame is pulled from the source once and cached until the next one is asked for.  With
+    `synchronized` a client that runs ahead of the others raises SynchronizationError (the test
+    counts how often the cached frame has been handed out); a client asking for any frame but
+    the cached or the next one always does."""
+
+    def __init__(self, source, synchronized=True, client_count=None):
+        self.synchronized = synchronized
+        self._client_count = client_count
+        self._clients = []
+        self._frame = None
+        self._frame_index = -1
+        self._retrieve_count = np.inf          # how often the cached frame has been handed out
+        self.state = "normal"
+        super(VideoFork, self).__init__(source)
+
+    @property
+    def client_count(self):
+        return len(self._clients) if self._client_count is None else self._client_count
+
+    def set_frame_pos(self, index):
+        """positions the fork and all of its clients"""
+        if index < 0:
+            index += self.frame_count
+        super(VideoFork, self).set_frame_pos(index)
+        for client in self._clients:
+            client.set_frame_pos(index)
+        self._frame = None
+        self._frame_index = index - 1
+
+    def get_frame(self, index):
+        """frame `index` for a client: the cached frame, or the next one of the source"""
+        if self.state == "aborting":
+            raise SystemExit("Another client of the VideoFork requested to abort the iteration.")
+        if index < 0:
+            index += self.frame_count
+        if index == self._frame_index:
+            self._retrieve_count += 1
+        elif index == self._frame_index + 1:
+            if self.synchronized and self._retrieve_count < self.client_count:
+                raise SynchronizationError("The other clients have not yet read the previous frame.")
+            self._frame_index = index
+            try:
+                self._frame = self.get_next_frame()
+            except (StopIteration, IndexError):
+                self._frame = StopIteration
+            self._retrieve_count = 1
+        else:
+            raise SynchronizationError("The clients of the video fork ran out of sync. The parent "
+                                       "process is at frame %d, while one client requested frame %d"
+                                       % (self._frame_index, index))
+        return self._frame
+
+    def clear(self):
+        """ends the iteration and forgets all clients (they may still read the cached frame)"""
+        self._clients = []
+
+    def abort_iteration(self):
+        """sends SystemExit to all other clients"""
+        self.state = "aborting"
+        super(VideoFork, self).abort_iteration()
+
+    def __iter__(self):
+        raise RuntimeError("Cannot iterate over a VideoFork. Use the get_client() method to get an "
+                           "iterable client.")
+
+    def get_client(self):
+        """a new client that can be iterated"""
+        if self._client_count is not None and len(self._clients) >= self._client_count:
+            raise ValueError("We already registered %d clients." % self._client_count)
+        client = _VideoForkClient(self)
+        self._clients.append(client)
+        self._retrieve_count = np.inf
+        return client

@@ -268,6 +268,43 @@ def resize(frames, size, interpolation="linear", color=False):
     return out[0] if single else out
 
 
+_DTYPE_CODES = {np.dtype(np.uint8): _hip.VA_U8, np.dtype(np.float32): _hip.VA_F32,
+                np.dtype(np.float64): _hip.VA_F64}
+
+
+def normalize_any(frames, fmin, fmax, alpha, tmin, dtype):
+    """FilterNormalize for uint8 / float32 frames and uint8 / float32 / float64 targets
+    (video/filters.py:126-132): clip, (f - fmin)*alpha + tmin in float64, astype(dtype)"""
+    a = np.ascontiguousarray(frames)
+    dtype = np.dtype(dtype)
+    if a.dtype not in (np.uint8, np.float32) or dtype not in _DTYPE_CODES:
+        raise TypeError("normalize: %s -> %s is not supported on the GPU path" % (a.dtype, dtype))
+    src = _upload(a)
+    dst = _take(a.size * dtype.itemsize)
+    try:
+        check(_hip.lib().va_normalize(src.ptr, _DTYPE_CODES[a.dtype], dst.ptr, _DTYPE_CODES[dtype], a.size,
+                                      float(fmin), float(fmax), float(alpha), float(tmin), None))
+        return dst.download(a.shape, dtype)
+    finally:
+        _give(src, dst)
+
+
+def gaussian_noise(shape, dtype=np.float64, mean=0.0, std=1.0, seed=0, first_index=0):
+    """`mean + std*randn(*shape)` produced on the GPU (VideoGaussianNoise, video/io/computed.py:36-41):
+    sample i of the seeded stream is a function of (seed, first_index + i) only"""
+    dtype = np.dtype(dtype)
+    if dtype not in _DTYPE_CODES:
+        raise TypeError("gaussian_noise: dtype %s is not supported on the GPU path" % dtype)
+    count = int(np.prod(shape))
+    dst = _take(max(count, 1) * dtype.itemsize)
+    try:
+        check(_hip.lib().va_gaussian_noise(dst.ptr, _DTYPE_CODES[dtype], count, float(mean), float(std),
+                                           int(seed) & (2 ** 64 - 1), int(first_index), None))
+        return dst.download(tuple(shape), dtype)
+    finally:
+        _give(dst)
+
+
 def morph(frames, op, shape="rect", ksize=3, implementation=None):
     """cv2.erode / cv2.dilate (video/analysis/image.py:248-251) on (H,W) or (N,H,W) uint8.
     implementation='bits' runs the bit-packed kernel of the pipeline (binary masks only)."""
