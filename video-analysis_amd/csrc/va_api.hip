@@ -673,8 +673,12 @@ int va_image_statistics_u8(const uint8_t *src, double *mean_out, double *var_out
     int rc = make_row_spans(kernel == 0 ? VA_SHAPE_RECT : VA_SHAPE_ELLIPSE, 2 * ksize + 1, &se);
     if (rc)
         return rc;
+    ScratchLease scratch;
+    rc = scratch.acquire(image_statistics_scratch_bytes(n, h, w), as_stream(stream));
+    if (rc)
+        return rc;
     return launch_image_statistics(src, mean_out, var_out, n, h, w, se, prior, exclude_center,
-                                   as_stream(stream));
+                                   scratch.ptr, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------ contour

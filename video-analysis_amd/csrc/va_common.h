@@ -167,9 +167,10 @@ int launch_detect_peaks(const uint8_t *src, uint8_t *dst, int n, int h, int w, i
                         hipStream_t st);
 int launch_thinning_step(const uint8_t *img, uint8_t *eroded, uint8_t *skel, int n, int h, int w,
                          unsigned long long *nonzero, hipStream_t st);
+size_t image_statistics_scratch_bytes(int n, int h, int w);
 int launch_image_statistics(const uint8_t *src, double *mean_out, double *var_out, int n, int h,
                             int w, const RowSpans &se, double prior, int exclude_center,
-                            hipStream_t st);
+                            void *scratch, hipStream_t st);
 
 // the whole op sequence in one kernel (register-streaming for one or two small rectangles,
 // LDS-resident otherwise)

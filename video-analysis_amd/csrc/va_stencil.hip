@@ -96,6 +96,7 @@ thinning_step_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ erod
 // get_image_statistics: window sums of (img - prior) and its square over a row-span element
 // with zero border (cv2.boxFilter(normalize=False) / cv2.filter2D(ellipse), BORDER_CONSTANT):
 //   mean = s1/count + prior ; var = (s2 - s1^2/count)/(count - 1)
+// Generic fallback (frames wider than 65536 pixels): O(window area) float64 additions per pixel.
 __global__ void __launch_bounds__(kBlock)
 image_statistics_kernel(const uint8_t *__restrict__ src, double *__restrict__ mean_out,
                         double *__restrict__ var_out, int h, int w, size_t total, RowSpans se,
@@ -133,6 +134,97 @@ image_statistics_kernel(const uint8_t *__restrict__ src, double *__restrict__ me
         var_out[e] = (s2 - s1 * s1 / count) / (count - 1.0);
 }
 
+// The fast path: the structuring element is a set of horizontal spans, so a window sum is a sum
+// over the window's rows of (prefix[x1 + 1] - prefix[x0]).  Pass 1 writes, per image row, the
+// exclusive prefix sums of img and img^2 (exact integers: uint32 holds 65025 * 65536); pass 2
+// needs 4 loads per window row instead of one load and two float64 additions per window PIXEL,
+// and forms  sum(img - prior) = S1 - N prior,  sum((img - prior)^2) = S2 - 2 prior S1 + N prior^2
+// with N = the number of in-image pixels under the element (zero border).  For integer priors
+// every quantity is an exact integer below 2^53, i.e. the results equal the direct sums bit for
+// bit; for fractional priors they agree to rounding (1e-12 relative on the mean).
+__global__ void __launch_bounds__(kBlock)
+row_prefix_kernel(const uint8_t *__restrict__ src, uint32_t *__restrict__ p1, uint32_t *__restrict__ p2, int w,
+                  size_t total_rows)
+{
+    const size_t row = (size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (row >= total_rows)
+        return;
+    const int lane = threadIdx.x & 63;
+    const uint8_t *s = src + row * (size_t)w;
+    uint32_t *o1 = p1 + row * (size_t)(w + 1), *o2 = p2 + row * (size_t)(w + 1);
+    const int per = (w + kWave - 1) / kWave;            // consecutive pixels per lane
+    const int xa = min(lane * per, w), xb = min(xa + per, w);
+    uint32_t a1 = 0, a2 = 0;
+    for (int x = xa; x < xb; x++) {
+        const uint32_t v = s[x];
+        a1 += v;
+        a2 += v * v;
+    }
+    uint32_t e1 = a1, e2 = a2;                          // inclusive scan over the lanes' totals
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t t1 = __shfl_up(e1, d, kWave), t2 = __shfl_up(e2, d, kWave);
+        if (lane >= d) {
+            e1 += t1;
+            e2 += t2;
+        }
+    }
+    uint32_t r1 = e1 - a1, r2 = e2 - a2;                // exclusive: sum of everything left of xa
+    for (int x = xa; x < xb; x++) {
+        o1[x] = r1;
+        o2[x] = r2;
+        const uint32_t v = s[x];
+        r1 += v;
+        r2 += v * v;
+    }
+    if (xb == w) {          // the lane(s) whose range ends at the row end hold the row total
+        o1[w] = r1;
+        o2[w] = r2;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+image_statistics_prefix_kernel(const uint8_t *__restrict__ src, const uint32_t *__restrict__ p1,
+                               const uint32_t *__restrict__ p2, double *__restrict__ mean_out,
+                               double *__restrict__ var_out, int h, int w, size_t total, RowSpans se,
+                               double prior, int exclude_center, double count)
+{
+    size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= total)
+        return;
+    const int x = (int)(e % w);
+    const size_t rowi = e / w;
+    const int y = (int)(rowi % h);
+    const size_t frow0 = rowi - y;                      // first row of this frame
+    long long S1 = 0, S2 = 0, N = 0;
+    for (int i = 0; i < se.ksize; i++) {
+        const int yy = y + i - se.anchor;
+        if (yy < 0 || yy >= h)
+            continue;
+        int x0 = x + se.lo[i] - se.anchor, x1 = x + se.hi[i] - se.anchor;     // [x0, x1)
+        x0 = x0 < 0 ? 0 : x0;
+        x1 = x1 > w ? w : x1;
+        if (x1 <= x0)
+            continue;
+        const size_t base = (frow0 + yy) * (size_t)(w + 1);
+        S1 += (long long)(p1[base + x1] - p1[base + x0]);
+        S2 += (long long)(p2[base + x1] - p2[base + x0]);
+        N += x1 - x0;
+    }
+    if (exclude_center) {
+        const long long c = src[e];
+        S1 -= c;
+        S2 -= c * c;
+        N -= 1;
+    }
+    const double dS1 = (double)S1, dN = (double)N;
+    const double s1 = dS1 - dN * prior;
+    const double s2 = ((double)S2 - 2.0 * prior * dS1) + dN * prior * prior;
+    mean_out[e] = s1 / count + prior;
+    if (var_out)
+        var_out[e] = (s2 - s1 * s1 / count) / (count - 1.0);
+}
+
 }  // namespace
 
 int launch_detect_peaks(const uint8_t *src, uint8_t *dst, int n, int h, int w, int include_plateaus,
@@ -160,9 +252,16 @@ int launch_thinning_step(const uint8_t *img, uint8_t *eroded, uint8_t *skel, int
     return VA_OK;
 }
 
+size_t image_statistics_scratch_bytes(int n, int h, int w)
+{
+    if (w > 65536)
+        return 256;                                     // (generic kernel: no scratch)
+    return 2 * (size_t)n * h * ((size_t)w + 1) * sizeof(uint32_t) + 256;
+}
+
 int launch_image_statistics(const uint8_t *src, double *mean_out, double *var_out, int n, int h,
                             int w, const RowSpans &se, double prior, int exclude_center,
-                            hipStream_t st)
+                            void *scratch, hipStream_t st)
 {
     size_t total = (size_t)n * h * w;
     if (total == 0)
@@ -172,6 +271,16 @@ int launch_image_statistics(const uint8_t *src, double *mean_out, double *var_ou
         count += se.hi[i] > se.lo[i] ? se.hi[i] - se.lo[i] : 0;
     if (exclude_center)
         count -= 1;
+    if (w <= 65536 && scratch) {
+        const size_t rows = (size_t)n * h;
+        uint32_t *p1 = (uint32_t *)scratch, *p2 = p1 + rows * ((size_t)w + 1);
+        row_prefix_kernel<<<cdiv((long long)rows, kBlock / kWave), kBlock, 0, st>>>(src, p1, p2, w, rows);
+        VA_LAUNCH_CHECK("row_prefix_kernel");
+        image_statistics_prefix_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(
+            src, p1, p2, mean_out, var_out, h, w, total, se, prior, exclude_center, count);
+        VA_LAUNCH_CHECK("image_statistics_prefix_kernel");
+        return VA_OK;
+    }
     image_statistics_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(
         src, mean_out, var_out, h, w, total, se, prior, exclude_center, count);
     VA_LAUNCH_CHECK("image_statistics_kernel");
