@@ -32,7 +32,8 @@ for _p in (ROOT, PKG):
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (width, height, batch, sigma, thresh, morph ksize, blobs per frame, salt)
+    # name: (width, height, batch, sigma, thresh, morph ksize (0: no morphology AND no labelling:
+    #        the chain ends with the uint8 mask), blobs per frame, salt)
     "cfg3_1080p_full_chain": (1920, 1080, 256, 5.0, 20, 5, 40, 0.002),
     "cfg2_1080p_blur_thresh": (1920, 1080, 256, 5.0, 20, 0, 40, 0.0),
     "cfg4_4k_full_chain": (3840, 2160, 128, 5.0, 20, 5, 160, 0.002),
@@ -429,16 +430,22 @@ def main():
     if args.batch > 0:
         batch = args.batch
     frames = synth_batch(torch, device, w, h, batch, blobs, salt, seed=3 + rank)
-    labels = torch.empty((batch, h, w), dtype=torch.int32, device=device)
+    ccl = morph > 0               # BASELINE configs[1] / [0] stop at the thresholded mask
+    labels = torch.empty((batch, h, w), dtype=torch.int32, device=device) if ccl else None
+    mask = None if ccl else torch.empty((batch, h, w), dtype=torch.uint8, device=device)
     counts = torch.zeros((batch,), dtype=torch.int32, device=device)
     steps_morph = (("dilate", "rect", morph), ("erode", "rect", morph)) if morph else ()
     eng = FrameEngine(size=(w, h), max_batch=batch, background="mean", sigma=sigma, thresh=thresh,
-                      morphology=steps_morph, connectivity=4, device=dev_index)
+                      morphology=steps_morph, connectivity=4 if ccl else 0, device=dev_index)
     stream = torch.cuda.current_stream(device)
 
     def step():
-        eng.run_device(frames.data_ptr(), batch, None, None, labels.data_ptr(), counts.data_ptr(),
-                       None, stream.cuda_stream)
+        if ccl:
+            eng.run_device(frames.data_ptr(), batch, None, None, labels.data_ptr(), counts.data_ptr(),
+                           None, stream.cuda_stream)
+        else:
+            eng.run_device(frames.data_ptr(), batch, None, mask.data_ptr(), None, None, None,
+                           stream.cuda_stream)
         if world > 1:       # the path's only exchange: object counts of every shard, RCCL over xGMI
             return gather_counts(counts if args.backend == "nccl" else counts.cpu(), world * batch)
         return counts
@@ -474,10 +481,12 @@ def main():
     fps = total_frames / dt
     if rank == 0:
         px = w * h
-        chain_bytes_per_frame = px * 1 + px * 4 + 4          # SURVEY.md 8(d) cfg#3: 10 368 004 B @1080p
+        # frame in + int32 labels out + count (10 368 004 B @1080p), or + u8 mask out
+        chain_bytes_per_frame = px * 1 + px * 4 + 4 if ccl else px * 2
         stage_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(stage.items())}
         res = {
-            "metric": "frames/sec (bg-sub+blur+thresh+CCL) 1080p uint8",
+            "metric": ("frames/sec (bg-sub+blur+thresh+CCL) %s uint8" % ("1080p" if (w, h) == (1920, 1080) else "%dx%d" % (w, h)))
+                      if ccl else "frames/sec (bg-sub+blur+thresh) %dx%d uint8" % (w, h),
             "value": round(fps, 2),
             "unit": "frames/s",
             "n_gpus": world,
@@ -490,10 +499,10 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "%s: %dx%d uint8, batch %d/GPU, running-mean bg-sub (f64 state) + "
-                                   "sigma=%g Gaussian (q8.8) + threshold %d + %s + 4-connected "
-                                   "labelling + object counts; inputs resident in HBM"
+                                   "sigma=%g Gaussian (q8.8) + threshold %d + %s; inputs resident in HBM"
                                    % (args.workload, w, h, batch, sigma, thresh,
-                                      "%dx%d dilate/erode" % (morph, morph) if morph else "no morphology"),
+                                      "%dx%d dilate/erode + 4-connected labelling + object counts" % (morph, morph)
+                                      if morph else "uint8 mask out (no morphology, no labelling)"),
                        "frames_per_step_per_gpu": batch, "engine": eng.description,
                        "world_size": dist.get_world_size() if distributed else 1,
                        "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed

@@ -24,8 +24,10 @@ STAGE_OF_KERNEL = {
     "morph_fused_kernel": "morph_fused", "morph_stream_kernel": "morph_fused", "ccl_init_kernel": "ccl_init", "ccl_frame_kernel": "ccl_frame", "ccl_link_kernel": "ccl_link",
     "ccl_flatten_kernel": "ccl_flatten", "ccl_rowscan_kernel": "ccl_rowscan",
     "ccl_rank_kernel": "ccl_rank", "ccl_paint_kernel": "ccl_paint",
+    "ema_row_f32_kernel": "ema_row_f32", "col_march_f32_kernel": "col_f32",
 }
-WIDE_STREAM_READS = {"bg", "gauss_fused", "gauss_mfma"}      # 8-16 B/lane coalesced loads: FETCH_SIZE x 2
+# 8-16 B/lane coalesced streaming loads: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM)
+WIDE_STREAM_READS = {"bg", "gauss_fused", "gauss_mfma", "ema_row_f32", "col_f32"}
 
 
 def per_kernel(path):
@@ -57,6 +59,7 @@ def main():
     tpath = os.path.join(os.path.dirname(out_prefix), "traffic.json")
     allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
     allt[workload] = traffic
+    allt.setdefault("_source", {})[workload] = os.path.basename(out_prefix)
     json.dump(allt, open(tpath, "w"), indent=1, sort_keys=True)
     print(json.dumps(traffic, indent=1))
 
