@@ -143,6 +143,17 @@ int va_normalize_u8(const uint8_t *src_dev, uint8_t *dst_dev, size_t count, doub
  * any dtype, video/filters.py:101-135): clip, affine map in float64, C cast to the target */
 int va_normalize(const void *src_dev, int src_dtype, void *dst_dev, int dst_dtype, size_t count,
                  double fmin, double fmax, double alpha, double tmin, void *stream);
+/* FilterCrop -> FilterMonochrome -> FilterNormalize in ONE pass over the source frames, on the device
+ * (A5: the pointwise pre-stages of a chain, video/filters.py:238-248, 359-374, 126-132), so that a
+ * chain which starts with them feeds the engine without a host round trip:
+ *   crop = frame[top:top+height, left:left+width]; mono: -1 keep the channels, 0..2 that channel,
+ *   3 np.mean(axis=2).astype(uint8); normalize != 0: clip, (f - fmin)*alpha + tmin, astype(uint8).
+ * src (n, src_h, src_w, src_c) uint8 -> dst (n, height, width[, src_c when mono == -1]). */
+#define VA_MONO_KEEP (-1)
+#define VA_MONO_MEAN 3
+int va_prepare_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int src_h, int src_w, int src_c, int left,
+                  int top, int width, int height, int mono, int normalize, double fmin, double fmax,
+                  double alpha, double tmin, void *stream);
 /* replaces  self.mean + self.std*np.random.randn(*self._frame_shape), VideoGaussianNoise.get_frame,
  *           video/io/computed.py:36-41, on the device (N4): sample i of the stream is a pure
  * function of (seed, i) -- Philox4x32-10 counter, Box-Muller in float64 -- so any frame can be

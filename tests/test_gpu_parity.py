@@ -1140,3 +1140,54 @@ def test_fork_and_analysis_preprocessor_on_gpu(oracle):
     for i, d in enumerate(pre2):
         assert np.array_equal(d["blur"], oracle.gaussian_u8(clip[i], 2.0))
         assert np.array_equal(d["big"], oracle.threshold_u8(clip[i], 128))
+
+
+def test_pointwise_pre_stages_fold_into_the_engine(oracle):
+    """A5: FilterCrop -> FilterMonochrome -> FilterNormalize in front of GPU stages run as ONE device
+    pass inside the engine (va_prepare_u8) -- same frames as the filters applied one by one"""
+    from video import _hip, filters as F
+    from video._hip import DeviceBuffer, check
+    from video.io.memory import VideoMemory
+    rng = np.random.default_rng(33)
+    col = rng.integers(0, 256, (40, 90, 130, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[:90, :130]
+    for t in range(40):
+        col[t][(xx - 40 - t) ** 2 + (yy - 45) ** 2 <= 144] = (250, 240, 245)
+
+    def chain(src):
+        crop = F.FilterCrop(src, rect=(10, 8, 96, 72))
+        mono = F.FilterMonochrome(crop, "mean")
+        norm = F.FilterNormalize(mono, 20, 220, dtype=np.uint8)
+        return F.FilterMorphology(F.FilterThreshold(F.FilterBlur(F.FilterBackground(norm), 2), 25), "close", 3)
+
+    fused = chain(VideoMemory(col))
+    runner = fused._runner()
+    assert runner is not None and runner.engine.prepare is not None and runner._source.is_color
+    got = np.stack([np.array(f) for f in fused])
+    F._GpuStage.contract = False
+    try:
+        ref = np.stack([np.array(f) for f in chain(VideoMemory(col))])
+    finally:
+        F._GpuStage.contract = True
+    assert np.array_equal(got, ref)
+    # and against the oracle, stage by stage
+    c = col[:, 8:80, 10:106].astype(np.float64).sum(-1)
+    m = (c / 3.0).astype(np.uint8)
+    nm = ((np.clip(m.astype(np.float64), 20, 220) - 20) * (255 / 200.0) + 0).astype(np.int64).astype(np.uint8)
+    rmask, _, _, _ = oracle.chain_u8(nm, 2.0, 25, morph_ksize=3, connectivity=4)
+    assert np.array_equal(got, rmask)
+    assert np.array_equal(fused[17], rmask[17])
+    # channel pick through the crop, no normalisation, a single GPU stage on top
+    blue = F.FilterBlur(F.FilterCrop(VideoMemory(col), region="left", color_channel="b"), 2)
+    assert blue._runner() is not None
+    assert np.array_equal(np.stack([np.array(f) for f in blue]), oracle.gaussian_u8(col[:, :, :65, 0], 2.0))
+    # the kernel on its own: every mode
+    L = _hip.lib()
+    src = DeviceBuffer.from_array(col[:3])
+    dst = DeviceBuffer(3 * 72 * 96 * 3)
+    check(L.va_prepare_u8(src.ptr, dst.ptr, 3, 90, 130, 3, 10, 8, 96, 72, -1, 1, 20.0, 220.0, 255 / 200.0, 0.0, None))
+    keep = dst.download((3, 72, 96, 3), np.uint8)
+    want = ((np.clip(col[:3, 8:80, 10:106].astype(np.float64), 20, 220) - 20) * (255 / 200.0)).astype(np.int64).astype(np.uint8)
+    assert np.array_equal(keep, want)
+    assert L.va_prepare_u8(src.ptr, dst.ptr, 3, 90, 130, 3, 100, 8, 96, 72, -1, 0, 0.0, 0.0, 0.0, 0.0, None) != 0
+    src.free(); dst.free()

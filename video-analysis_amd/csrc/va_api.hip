@@ -488,6 +488,15 @@ int va_normalize(const void *src, int src_dtype, void *dst, int dst_dtype, size_
     return launch_normalize(src, src_dtype, dst, dst_dtype, count, fmin, fmax, alpha, tmin, as_stream(stream));
 }
 
+int va_prepare_u8(const uint8_t *src, uint8_t *dst, int n, int src_h, int src_w, int src_c, int left, int top,
+                  int width, int height, int mono, int normalize, double fmin, double fmax, double alpha,
+                  double tmin, void *stream)
+{
+    VA_ENTER();
+    return launch_prepare_u8(src, dst, n, src_h, src_w, src_c, left, top, width, height, mono, normalize, fmin,
+                             fmax, alpha, tmin, as_stream(stream));
+}
+
 int va_gaussian_noise(void *dst, int dtype, size_t count, double mean, double stdev, uint64_t seed,
                       uint64_t first_index, void *stream)
 {

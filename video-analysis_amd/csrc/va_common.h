@@ -197,6 +197,9 @@ int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, i
 // FilterNormalize for uint8 / float32 frames, any of the three target dtypes; seeded noise frames
 int launch_normalize(const void *src, int src_dtype, void *dst, int dst_dtype, size_t count, double fmin,
                      double fmax, double alpha, double tmin, hipStream_t st);
+int launch_prepare_u8(const uint8_t *src, uint8_t *dst, int n, int src_h, int src_w, int src_c, int left, int top,
+                      int width, int height, int mono, int normalize, double fmin, double fmax, double alpha,
+                      double tmin, hipStream_t st);
 int launch_gaussian_noise(void *dst, int dtype, size_t count, double mean, double stdev, uint64_t seed,
                           uint64_t first_index, hipStream_t st);
 // cv2.resize for uint8 frames (va_resize.hip); mode 0 nearest, 1 linear, 2 cubic, 3 area

@@ -29,6 +29,43 @@ normalize_kernel(const SRC *__restrict__ src, DST *__restrict__ dst, size_t coun
         dst[i] = (DST)v;
 }
 
+// FilterCrop -> FilterMonochrome -> FilterNormalize in one pass over the source frames (A5: the
+// pointwise pre-stages of the chain, fused with each other and run on the device inside the
+// engine, so a chain that starts with them needs no host round trip):
+//   crop      frame[top:top+height, left:left+width]            (video/filters.py:238-248)
+//   mono      3: np.mean(frame, axis=2).astype(uint8) (float64 mean, truncated); 0..2: that channel;
+//             -1: channels kept                                 (video/filters.py:359-374)
+//   normalize clip, (f - fmin)*alpha + tmin in float64, astype(uint8)   (video/filters.py:126-132)
+__global__ void __launch_bounds__(kBlock)
+prepare_u8_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int src_h, int src_w, int src_c,
+                  int left, int top, int width, int height, int mono, int out_c, int normalize, double fmin,
+                  double fmax, double alpha, double tmin, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total)
+        return;
+    const int ch = (int)(i % out_c);
+    const size_t p = i / out_c;
+    const int x = (int)(p % width), y = (int)((p / width) % height);
+    const size_t f = p / ((size_t)width * height);
+    const uint8_t *px = src + ((f * src_h + (top + y)) * (size_t)src_w + (left + x)) * src_c;
+    int v;
+    if (mono == 3) {
+        const double s = (double)px[0] + (double)px[1] + (double)px[2];
+        v = (int)(s / 3.0);
+    } else if (mono >= 0) {
+        v = px[mono];
+    } else {
+        v = px[ch];
+    }
+    if (normalize) {
+        double d = (double)v;
+        d = d < fmin ? fmin : (d > fmax ? fmax : d);
+        v = (int)((d - fmin) * alpha + tmin);
+    }
+    dst[i] = (uint8_t)v;
+}
+
 // Philox4x32-10 (Salmon et al., SC'11): counter-based, so sample i of the stream is a pure
 // function of (seed, i) -- any frame of the noise video can be produced on its own
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -107,6 +144,27 @@ int launch_normalize(const void *src, int src_dtype, void *dst, int dst_dtype, s
     }
 #undef VA_NORM
     VA_LAUNCH_CHECK("normalize_kernel");
+    return VA_OK;
+}
+
+int launch_prepare_u8(const uint8_t *src, uint8_t *dst, int n, int src_h, int src_w, int src_c, int left, int top,
+                      int width, int height, int mono, int normalize, double fmin, double fmax, double alpha,
+                      double tmin, hipStream_t st)
+{
+    VA_REQUIRE(src && dst && src != dst, "va_prepare_u8: src/dst must be distinct non-NULL");
+    VA_REQUIRE(n >= 0 && src_h > 0 && src_w > 0 && src_c >= 1 && src_c <= 4, "va_prepare_u8: bad source shape");
+    VA_REQUIRE(left >= 0 && top >= 0 && width > 0 && height > 0 && left + width <= src_w && top + height <= src_h,
+               "va_prepare_u8: rectangle (%d,%d,%d,%d) outside the %dx%d frame", left, top, width, height, src_w, src_h);
+    VA_REQUIRE(mono >= -1 && mono <= 3 && (mono < 0 || (mono == 3 ? src_c == 3 : mono < src_c)),
+               "va_prepare_u8: mono mode %d does not fit %d channels", mono, src_c);
+    const int out_c = mono < 0 ? src_c : 1;
+    const size_t total = (size_t)n * height * width * out_c;
+    if (total == 0)
+        return VA_OK;
+    prepare_u8_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(src, dst, src_h, src_w, src_c, left, top, width,
+                                                                        height, mono, out_c, normalize, fmin, fmax,
+                                                                        alpha, tmin, total);
+    VA_LAUNCH_CHECK("prepare_u8_kernel");
     return VA_OK;
 }
 

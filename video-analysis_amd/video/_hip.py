@@ -99,6 +99,7 @@ SIGNATURES = {
     "va_contour_workspace_bytes": (_sz, [_i, _i, _i]),
     "va_largest_contour": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "va_normalize": (_i, [_vp, _i, _vp, _i, _sz, _d, _d, _d, _d, _vp]),
+    "va_prepare_u8": (_i, [_vp, _vp] + [_i] * 10 + [_d, _d, _d, _d, _vp]),
     "va_gaussian_noise": (_i, [_vp, _i, _sz, _d, _d, C.c_uint64, C.c_uint64, _vp]),
     "va_resize_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "va_contour_moments": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

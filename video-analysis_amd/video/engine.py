@@ -18,10 +18,15 @@ class FrameEngine(object):
 
     def __init__(self, size, channels=1, dtype=np.uint8, max_batch=64, background=None,
                  bg_rate=0.02, sigma=0.0, thresh=None, maxval=255, morphology=(),
-                 connectivity=0, max_labels=0, device=None):
+                 connectivity=0, max_labels=0, device=None, prepare=None):
         """size = (width, height) as everywhere in the reference (video/io/base.py:40-55).
         background: None | 'mean' | 'ema' | 'static';  morphology: sequence of
-        (op, shape, ksize) with op in {'erode','dilate'}, shape in {'rect','cross','ellipse'}."""
+        (op, shape, ksize) with op in {'erode','dilate'}, shape in {'rect','cross','ellipse'}.
+        prepare: optional dict describing the pointwise pre-stages FilterCrop -> FilterMonochrome
+        -> FilterNormalize, fused into one device pass in front of the chain (`run` then takes the
+        RAW source frames): {'src_size': (W0, H0), 'src_channels': 1|3, 'rect': (left, top, width,
+        height) | None, 'mono': None | 'mean' | 0..2, 'normalize': None | (fmin, fmax, alpha, tmin)};
+        `size` is the size AFTER the crop."""
         self.width, self.height = int(size[0]), int(size[1])
         self.channels = int(channels)
         self.dtype = np.dtype(dtype)
@@ -58,6 +63,23 @@ class FrameEngine(object):
         check(self._lib.va_pipeline_create(C.byref(cfg), C.byref(self._handle)))
         self.bg_mode = cfg.bg_mode
         self._dev = {}      # name -> DeviceBuffer cache for run()
+        self.prepare = None
+        if prepare is not None:
+            if self.dtype != np.uint8:
+                raise TypeError("prepare stages work on uint8 frames")
+            w0, h0 = (int(v) for v in prepare["src_size"])
+            c0 = int(prepare.get("src_channels", 1))
+            rect = prepare.get("rect") or (0, 0, w0, h0)
+            mono = prepare.get("mono")
+            mono_code = -1 if mono is None else (3 if mono == "mean" else int(mono))
+            out_c = c0 if mono_code < 0 else 1
+            if (int(rect[2]), int(rect[3])) != (self.width, self.height) or out_c != self.channels:
+                raise ValueError("prepare stages produce %dx%dx%d frames, the engine expects %dx%dx%d"
+                                 % (rect[2], rect[3], out_c, self.width, self.height, self.channels))
+            norm = prepare.get("normalize")
+            self.prepare = dict(src_shape=(h0, w0) + ((c0,) if c0 > 1 else ()), h0=h0, w0=w0, c0=c0,
+                                rect=tuple(int(v) for v in rect), mono=mono_code,
+                                norm=None if norm is None else tuple(float(v) for v in norm))
 
     # ------------------------------------------------------------------ properties
     @property
@@ -88,8 +110,9 @@ class FrameEngine(object):
         """frames: (n, H, W[, C]) array; returns a dict with the requested outputs among
         'filtered', 'mask', 'labels', 'counts', 'stats'"""
         arr = np.ascontiguousarray(frames, self.dtype)
-        if arr.shape[1:] != self.frame_shape:
-            raise ValueError("frames of shape %r do not match %r" % (arr.shape[1:], self.frame_shape))
+        in_shape = self.prepare["src_shape"] if self.prepare else self.frame_shape
+        if arr.shape[1:] != in_shape:
+            raise ValueError("frames of shape %r do not match %r" % (arr.shape[1:], in_shape))
         n = arr.shape[0]
         if n > self.max_batch:
             raise ValueError("batch of %d exceeds max_batch=%d" % (n, self.max_batch))
@@ -98,8 +121,19 @@ class FrameEngine(object):
         if unknown:
             raise ValueError("unknown outputs %r" % sorted(unknown))
         px = self.width * self.height
-        src = self._buf("src", arr.nbytes)
-        src.upload(arr)
+        if self.prepare:                    # crop / monochrome / normalize: one device pass, no host round trip
+            pr = self.prepare
+            raw = self._buf("raw", arr.nbytes)
+            raw.upload(arr)
+            src = self._buf("src", n * px * self.channels)
+            nm = pr["norm"] or (0.0, 0.0, 0.0, 0.0)
+            check(self._lib.va_prepare_u8(raw.ptr, src.ptr, n, pr["h0"], pr["w0"], pr["c0"], pr["rect"][0],
+                                          pr["rect"][1], pr["rect"][2], pr["rect"][3], pr["mono"],
+                                          1 if pr["norm"] else 0, nm[0], nm[1], nm[2], nm[3], None))
+            arr = np.empty((n,) + self.frame_shape, self.dtype)     # (shape of the prepared frames)
+        else:
+            src = self._buf("src", arr.nbytes)
+            src.upload(arr)
         ptr = {}
         if "filtered" in want:
             ptr["filtered"] = self._buf("filtered", arr.nbytes)

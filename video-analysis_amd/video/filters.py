@@ -232,8 +232,34 @@ class _GpuStage(object):
             stages.append(node)
             node = node._source
         stages.reverse()
+        # pointwise pre-stages below the first engine stage fold into one device pass in front of the
+        # chain (FrameEngine(prepare=...)): [FilterCrop] -> [FilterMonochrome] -> [FilterNormalize with
+        # explicit uint8 limits], in this order, none of them listened to
+        prepare, pre_nodes = None, 0
+        norm = mono = rect = None
+        if isinstance(node, FilterNormalize) and not node._listeners and node._fmin is not None \
+                and node._fmax is not None and node._dtype == np.uint8:
+            tmin, tmax = get_color_range(np.uint8)
+            norm = (node._fmin, node._fmax, (tmax - tmin) / (float(node._fmax) - float(node._fmin)), tmin)
+            node, pre_nodes = node._source, pre_nodes + 1
+        if isinstance(node, FilterMonochrome) and not node._listeners and node._source.is_color:
+            mono = node.mode
+            node, pre_nodes = node._source, pre_nodes + 1
+        if isinstance(node, FilterCrop) and not node._listeners and \
+                (node.color_channel is None or (mono is None and node._source.is_color)):
+            rect = node.rect
+            if node.color_channel is not None:
+                mono = node.color_channel
+            node, pre_nodes = node._source, pre_nodes + 1
+        if pre_nodes:
+            if (mono is None) == bool(node.is_color):      # colour frames must end up monochrome
+                node, pre_nodes = stages[0]._source, 0
+            else:
+                prepare = dict(src_size=node.size, src_channels=3 if node.is_color else 1, rect=rect,
+                               mono=mono, normalize=norm)
         root = node
-        if not self.contract or len(stages) < 2 or root.is_color or not root.seekable:
+        if not self.contract or len(stages) + pre_nodes < 2 or not root.seekable or \
+                (root.is_color and prepare is None):
             return None         # (batched prefetch needs random access: fork clients, pipes stay per-frame)
         order = {"background": 0, "blur": 1, "threshold": 2, "morphology": 3}
         kinds = [st._stage()[0] for st in stages]
@@ -243,7 +269,7 @@ class _GpuStage(object):
         if "morphology" in kinds and "threshold" not in kinds:
             return None                     # the engine's morphology works on thresholded masks
         args = dict(background=None, rate=0.02, sigma=0.0, threshold=None, morphology=(),
-                    connectivity=0, static_background=None)
+                    connectivity=0, static_background=None, prepare=prepare, size=stages[0]._source.size)
         maxval = 255
         steps = []
         for st in stages:
@@ -292,7 +318,7 @@ class _GpuStage(object):
                     plan["root"], background=a["background"], rate=a["rate"], sigma=a["sigma"],
                     threshold=a["threshold"], morphology=a["morphology"], connectivity=0,
                     output=plan["output"], batch=self.chain_batch, extra_outputs=extra,
-                    static_background=a["static_background"])
+                    static_background=a["static_background"], prepare=a["prepare"], size=a["size"])
                 self._runner_obj._engine_args["maxval"] = plan["maxval"]
                 self._runner_notify = plan["notify"]
             self._runner_key = key
@@ -703,8 +729,9 @@ class FilterAnalysisChain(_SequentialStateFilter):
 
     def __init__(self, source, background="mean", rate=0.02, sigma=5.0, threshold=20,
                  morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4,
-                 output="mask", batch=32, max_labels=0, extra_outputs=(), static_background=None):
-        if source.is_color:
+                 output="mask", batch=32, max_labels=0, extra_outputs=(), static_background=None,
+                 prepare=None, size=None):
+        if source.is_color and prepare is None:
             raise ValueError("FilterAnalysisChain expects a monochrome video")
         if output not in ("mask", "labels", "filtered"):
             raise ValueError("output must be 'mask', 'labels' or 'filtered'")
@@ -715,15 +742,15 @@ class FilterAnalysisChain(_SequentialStateFilter):
         self._static_background = static_background
         self.last_results = {}
         self.batch = int(batch)
-        self._engine_args = dict(size=source.size, channels=1, dtype=np.uint8, max_batch=self.batch,
-                                 background=background, bg_rate=rate, sigma=sigma, thresh=threshold,
-                                 morphology=morphology, connectivity=connectivity,
-                                 max_labels=max_labels)
+        self._engine_args = dict(size=source.size if size is None else size, channels=1, dtype=np.uint8,
+                                 max_batch=self.batch, background=background, bg_rate=rate, sigma=sigma,
+                                 thresh=threshold, morphology=morphology, connectivity=connectivity,
+                                 max_labels=max_labels, prepare=prepare)
         self._engine = None
         self._cache = {}            # frame index -> dict of per-frame results
         self.last_count = None
         self.last_stats = None
-        super(FilterAnalysisChain, self).__init__(source, is_color=False)
+        super(FilterAnalysisChain, self).__init__(source, size=size, is_color=False)
 
     @property
     def engine(self):
