@@ -524,7 +524,13 @@ int va_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op, i
     int rc = make_row_spans(shape, ksize, &se);
     if (rc)
         return rc;
-    return launch_morph_u8(src, dst, n, h, w, op, se, as_stream(stream));
+    ScratchLease scratch;
+    if (shape == VA_SHAPE_RECT && ksize >= 3 && n > 0) {
+        rc = scratch.acquire((size_t)n * h * w, as_stream(stream));
+        if (rc)
+            return rc;
+    }
+    return launch_morph_u8(src, dst, n, h, w, op, se, as_stream(stream), (uint8_t *)scratch.ptr);
 }
 
 // test hook: morphology on the bit-packed representation used inside the pipeline

@@ -157,8 +157,9 @@ struct RowSpans {
     int8_t hi[64];
 };
 int make_row_spans(int shape, int ksize, RowSpans *out);
+// scratch (n*h*w bytes, nullable): lets rectangular elements run as a row pass + a column pass
 int launch_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op,
-                    const RowSpans &se, hipStream_t st);
+                    const RowSpans &se, hipStream_t st, uint8_t *scratch = nullptr);
 int launch_morph_bits(const uint32_t *src, uint32_t *dst, int n, int h, int w, int op,
                       const RowSpans &se, hipStream_t st);
 
