@@ -683,10 +683,19 @@ __device__ __forceinline__ void scan_rows(int *rowbase, int h, int *s_part, int 
     __syncthreads();
 }
 
+// `table` != nullptr: instead of sweeping the rows a third time to drop one sparse word per run into
+// the label image (which the paint pass then has to chase: L[first pixel] -> L[root]), the frame's
+// labels leave as a compact table -- label of run id i at table[f * table_stride + i], first run id
+// of row y at rowbase_g[f * h + y], mode[f] = 1 -- written linearly straight from the LDS forest.
+// The paint pass numbers the runs of its row the same way (row base + run starts to the left) and
+// needs ONE cached load per run.  Frames in large-frame mode keep the sparse convention (mode 0);
+// so does the contour tracer, which reads roots at first pixels (table == nullptr).
 template <bool CONN8, int NCH, int RPW>
 __global__ void __launch_bounds__(kFrameThreads)
 ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
-                 int32_t *__restrict__ counts, int h, int w, int w32, FrameLayout lay, int vec)
+                 int32_t *__restrict__ counts, int h, int w, int w32, FrameLayout lay, int vec,
+                 int32_t *__restrict__ table, int table_stride, int32_t *__restrict__ rowbase_g,
+                 int32_t *__restrict__ mode)
 {
     __shared__ __attribute__((aligned(16))) int s_mem[kFrameLdsWords];
     __shared__ int s_part[kFrameWaves];
@@ -772,6 +781,8 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     scan_rows(rowbase, h, s_part, &s_total);
     const int nruns = s_total;
 
+    if (table && tid == 0)
+        mode[f] = nruns <= lay.lds_runs ? 1 : 0;
     if (nruns > lay.lds_runs) {
         // ---- large-frame mode: forest in the label image, same passes as the chip-wide path ---
         for (int it = 0; it < sweeps; it++) {
@@ -934,6 +945,20 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
             parent[i] = -(++k);            // roots: -(label); only this thread touches entry i
     __syncthreads();
 
+    if (table) {
+        // ---- 5a. the labels leave as a table (coalesced), with the first run id of every row --------
+        int32_t *tf = table + (size_t)f * table_stride;
+        for (int i = tid; i < nruns; i += kFrameThreads) {
+            int v = parent[i];
+            if (v >= 0)
+                v = parent[v];                 // a root's entry: -(label)
+            tf[i] = -v;
+        }
+        int32_t *rb = rowbase_g + (size_t)f * h;
+        for (int y = tid; y < h; y += kFrameThreads)
+            rb[y] = rowbase[y];
+        return;
+    }
     // ---- 5. one sparse write per run: what the paint pass and the contour tracer read ---------------
     // The next sweep step's row loads are issued BEFORE this step's stores, and the stores are
     // branch-free buffer stores (out-of-range offset = dropped): vmcnt retires in order, so loads
@@ -1025,7 +1050,8 @@ template <bool STATS>
 __global__ void __launch_bounds__(kBlock)
 ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
                  int w32, size_t total_rows, int64_t *__restrict__ stats, int max_labels,
-                 int vec_ok)
+                 int vec_ok, const int32_t *__restrict__ table, int table_stride,
+                 const int32_t *__restrict__ rowbase_g, const int32_t *__restrict__ mode)
 {
     __shared__ uint32_t s_m[kRowsPerBlock][kWave];
     __shared__ uint32_t s_heads[kRowsPerBlock][kWave];
@@ -1038,16 +1064,39 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     int32_t *out = L + (size_t)c.y * w;
     int64_t *fstats = STATS ? stats + (size_t)c.f * max_labels * VA_STATS_STRIDE : nullptr;
     int carry = 0;  // label of the run that covers the last pixel of the previous chunk
+    // run-table mode (see ccl_frame_kernel): labels come from table[run id], run ids from the row's
+    // first id plus the run starts to the left (wave scan over the row's words)
+    const bool use_table = table != nullptr && c.valid && mode[c.f] != 0;      // wave-uniform
+    const int32_t *tf = use_table ? table + (size_t)c.f * table_stride : nullptr;
+    int id_next = use_table ? rowbase_g[c.row] : 0;       // id of the next run that starts in this row
 
     for (int w0 = 0; w0 < w32; w0 += kWave) {
         // ---- phase A: lane <-> word; label of every run (segment) inside the word
         const int wi = w0 + c.lane;
         uint32_t m = 0, heads = 0;
         int last_label = 0;
+        uint32_t prev_bit = 0, starts_w = 0;
         if (c.valid && wi < w32) {
             m = row[wi];
-            const uint32_t prev = wi > 0 ? row[wi - 1] >> 31 : 0u;
-            const uint32_t starts = m & ~((m << 1) | prev);
+            prev_bit = wi > 0 ? row[wi - 1] >> 31 : 0u;
+            starts_w = m & ~((m << 1) | prev_bit);
+        }
+        int id_word = 0;                                   // id of the first run that starts in this word
+        if (use_table) {
+            const int cnt = __popc(starts_w);
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const int t = __shfl_up(incl, o, kWave);
+                if (c.lane >= o)
+                    incl += t;
+            }
+            id_word = id_next + incl - cnt;
+            id_next += __shfl(incl, kWave - 1, kWave);
+        }
+        if (c.valid && wi < w32) {
+            const uint32_t prev = prev_bit;
+            const uint32_t starts = starts_w;
             heads = starts | (m & 1u);
             uint32_t hb = heads;
             int k = 0;
@@ -1055,7 +1104,12 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                 const int b = __ffs(hb) - 1;
                 hb &= hb - 1;
                 int lab;
-                if (b == 0 && prev) {
+                if (use_table) {
+                    // the j-th start of the word is run id_word + j; a run entering from the left is
+                    // the last one started before this word
+                    const int j = __popc(starts & ((1u << b) - 1u));
+                    lab = tf[(b == 0 && prev) ? id_word - 1 : id_word + j];
+                } else if (b == 0 && prev) {
                     // the run enters from the left: look for its first pixel inside this chunk
                     int start = -1;
                     for (int ww = wi - 1; ww >= w0; --ww) {
@@ -1428,11 +1482,12 @@ bool ccl_frame_kernel_used(int n, int h, int w)
     return true;
 }
 
-// [row_cnt][row_off]
+// [row_cnt][row_off][run-label tables of the per-frame kernel][mode]
+static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t ccl_rows_workspace_bytes(int n, int h)
 {
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    return 2 * up((size_t)n * h * sizeof(int32_t));
+    return 2 * up256((size_t)n * h * sizeof(int32_t)) + up256((size_t)n * kFrameLdsWords * sizeof(int32_t)) +
+           up256((size_t)n * sizeof(int32_t));
 }
 
 size_t ccl_workspace_bytes(int n, int h, int w)
@@ -1467,6 +1522,10 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     VA_REQUIRE(ws_bytes >= ccl_rows_workspace_bytes(n, h), "label: workspace too small");
     int32_t *row_cnt = (int32_t *)workspace;
     int32_t *row_off = (int32_t *)((char *)workspace + up(total_rows * sizeof(int32_t)));
+    int32_t *run_table = (int32_t *)((char *)workspace + 2 * up(total_rows * sizeof(int32_t)));
+    int32_t *frame_mode = (int32_t *)((char *)run_table + up((size_t)n * kFrameLdsWords * sizeof(int32_t)));
+    bool table_mode = false;                 // set when the per-frame kernel hands its labels over as tables
+    int table_stride = 0;
     const int grid = cdiv((long long)total_rows, kRowsPerBlock);          // paint: wave = row
 
     const dim3 sgrid_all((unsigned)cdiv(h, kSparseRowsPerBlock), (unsigned)min(n, 4096));
@@ -1502,8 +1561,12 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
             lay.lds_runs = min(lay.lds_runs, g_ccl_lds_runs);
         const int vec = (w32 % 4 == 0) && aligned(bits, 16);
         const int nch = span_chunks(w32, rpw);
-#define VA_FRAME_LAUNCH(C8, NCH, RPW) \
-    ccl_frame_kernel<C8, NCH, RPW><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, vec)
+        table_mode = paint;                  // (the contour tracer reads roots in the label image instead)
+        table_stride = lay.lds_runs;
+#define VA_FRAME_LAUNCH(C8, NCH, RPW)                                                                       \
+    ccl_frame_kernel<C8, NCH, RPW><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, vec,  \
+                                                                 table_mode ? run_table : nullptr, lay.lds_runs, \
+                                                                 row_off, frame_mode)
 #define VA_FRAME_CASE(NCH, RPW)                 \
     if (nch == NCH && rpw == RPW) {             \
         if (connectivity == 8)                  \
@@ -1531,10 +1594,12 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
         VA_LAUNCH_CHECK("stats_init_kernel");
         VA_MARK("stats_init");
         ccl_paint_kernel<true><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows, stats,
-                                                       max_labels, vec);
+                                                       max_labels, vec, table_mode ? run_table : nullptr,
+                                                       table_stride, row_off, frame_mode);
     } else {
         ccl_paint_kernel<false><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows,
-                                                        nullptr, 0, vec);
+                                                        nullptr, 0, vec, table_mode ? run_table : nullptr,
+                                                        table_stride, row_off, frame_mode);
     }
     VA_LAUNCH_CHECK("ccl_paint_kernel");
     VA_MARK("ccl_paint");
