@@ -1083,16 +1083,24 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         }
         int id_word = 0;                                   // id of the first run that starts in this word
         if (use_table) {
+            // run starts in the words to the left: almost every word holds at most one start, so two
+            // ballots do (a full wave scan only for rows with a word that starts several runs)
             const int cnt = __popc(starts_w);
-            int incl = cnt;
+            const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2);
+            if (b2 == 0) {                                  // wave-uniform
+                id_word = id_next + __popcll(b1 & ((1ull << c.lane) - 1ull));
+                id_next += __popcll(b1);
+            } else {
+                int incl = cnt;
 #pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const int t = __shfl_up(incl, o, kWave);
-                if (c.lane >= o)
-                    incl += t;
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const int t = __shfl_up(incl, o, kWave);
+                    if (c.lane >= o)
+                        incl += t;
+                }
+                id_word = id_next + incl - cnt;
+                id_next += __shfl(incl, kWave - 1, kWave);
             }
-            id_word = id_next + incl - cnt;
-            id_next += __shfl(incl, kWave - 1, kWave);
         }
         if (c.valid && wi < w32) {
             const uint32_t prev = prev_bit;
@@ -1442,9 +1450,12 @@ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_
 // kernel whatever the batch size; g_ccl_lds_runs > 0 caps the per-frame kernel's run table
 static int g_ccl_path = 0;
 static int g_ccl_lds_runs = 0;
+static int g_ccl_sparse = 0;   // hook path 3: the library's choice of kernel, labels handed to the paint
+                               // pass as sparse words in the label image (the round-1 convention)
 void ccl_test_hook(int path, int lds_runs)
 {
-    g_ccl_path = path;
+    g_ccl_sparse = path == 3;
+    g_ccl_path = path == 3 ? 0 : path;
     g_ccl_lds_runs = lds_runs;
 }
 
@@ -1561,7 +1572,7 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
             lay.lds_runs = min(lay.lds_runs, g_ccl_lds_runs);
         const int vec = (w32 % 4 == 0) && aligned(bits, 16);
         const int nch = span_chunks(w32, rpw);
-        table_mode = paint;                  // (the contour tracer reads roots in the label image instead)
+        table_mode = paint && !g_ccl_sparse; // (the contour tracer reads roots in the label image instead)
         table_stride = lay.lds_runs;
 #define VA_FRAME_LAUNCH(C8, NCH, RPW)                                                                       \
     ccl_frame_kernel<C8, NCH, RPW><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, vec,  \
