@@ -759,16 +759,15 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         }
         wave_sync();
     };
-    auto stage_rows = [&](int y0) {
-        RowRegs rr;
-        issue_rows(y0, rr);
-        commit_rows(rr);
-    };
-
     // ---- 1. runs per row, exclusive scan -> first run id of every row -----------------------
+    // (the next step's rows are in flight while this step's are counted: one memory round trip
+    // per sweep step would otherwise be exposed 2 x 8.4 times per frame)
+    RowRegs rr1;
+    issue_rows(wv * RPW, rr1);
     for (int it = 0; it < sweeps; it++) {
         const int y0 = it * kRowsPerIter + wv * RPW;
-        stage_rows(y0);
+        commit_rows(rr1);
+        issue_rows(y0 + kRowsPerIter, rr1);        // clamped rows past the frame: harmless
         const FrameSpan c = frame_span<NCH, RPW>(y0, h, w32);
         uint32_t mw[NCH][kChunk + 2];
         load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
@@ -836,9 +835,12 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     };
 
     // ---- 3. link runs of row y with runs of row y-1 -----------------------------------------------
+    RowRegs rr3;
+    issue_rows(wv * RPW, rr3);
     for (int it = 0; it < sweeps; it++) {
         const int y0 = it * kRowsPerIter + wv * RPW;
-        stage_rows(y0);
+        commit_rows(rr3);
+        issue_rows(y0 + kRowsPerIter, rr3);
         const FrameSpan c = frame_span<NCH, RPW>(y0, h, w32);
         const bool act = c.valid && c.y > 0;
         uint32_t mw[NCH][kChunk + 2], uw[NCH][kChunk + 2];
@@ -1066,9 +1068,11 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     int carry = 0;  // label of the run that covers the last pixel of the previous chunk
     // run-table mode (see ccl_frame_kernel): labels come from table[run id], run ids from the row's
     // first id plus the run starts to the left (wave scan over the row's words)
-    const bool use_table = table != nullptr && c.valid && mode[c.f] != 0;      // wave-uniform
+    // (both loads are issued together: the row base must not wait for the mode word)
+    const int md = (table != nullptr && c.valid) ? mode[c.f] : 0;
+    int id_next = (table != nullptr && c.valid) ? rowbase_g[c.row] : 0;   // id of the next run that starts in this row
+    const bool use_table = md != 0;                                      // wave-uniform
     const int32_t *tf = use_table ? table + (size_t)c.f * table_stride : nullptr;
-    int id_next = use_table ? rowbase_g[c.row] : 0;       // id of the next run that starts in this row
 
     for (int w0 = 0; w0 < w32; w0 += kWave) {
         // ---- phase A: lane <-> word; label of every run (segment) inside the word
