@@ -222,3 +222,15 @@ def test_stress_slice_gaussian_f32(oracle):
         ref = oracle.gaussian_f32(f, sigma)
         got = ops.gaussian_blur(f, sigma, color=(c == 3))
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (shape, sigma)
+
+
+def test_stress_slice_round2_paths(oracle):
+    """a bounded, seeded slice of tools/stress_misc.py: float32 EMA + blur through the pipeline at random
+    shapes with split batches, cv2.resize in every mode, contour moments of traced contours"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stress_misc
+    rng = np.random.default_rng(424242)
+    for fn in (stress_misc.case_f32_pipeline, stress_misc.case_resize, stress_misc.case_contour_moments):
+        for _ in range(40):
+            ok, desc = fn(rng)
+            assert ok, desc
