@@ -1053,13 +1053,30 @@ __global__ void __launch_bounds__(kBlock)
 ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
                  int w32, size_t total_rows, int64_t *__restrict__ stats, int max_labels,
                  int vec_ok, const int32_t *__restrict__ table, int table_stride,
-                 const int32_t *__restrict__ rowbase_g, const int32_t *__restrict__ mode)
+                 const int32_t *__restrict__ rowbase_g, const int32_t *__restrict__ mode, int xcd_frames)
 {
     __shared__ uint32_t s_m[kRowsPerBlock][kWave];
     __shared__ uint32_t s_heads[kRowsPerBlock][kWave];
     __shared__ int32_t s_lab[kRowsPerBlock][kWave][16];
 
     RowCtx c = row_ctx(h, total_rows);
+    if (xcd_frames) {
+        // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs and the per-frame
+        // labelling kernel ran frame f on XCD f % 8 (one workgroup per frame), so the run table, the
+        // row bases and the mask rows of a frame are still in THAT XCD's L2: give every XCD the rows
+        // of its own frames (frames come in groups of 8; xcd_frames = blocks per frame)
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int fr = (q / xcd_frames) * 8 + xcd;
+        const int rb = (q % xcd_frames) * kRowsPerBlock + (threadIdx.x >> 6);
+        c.f = fr;
+        c.y = rb;
+        c.valid = rb < h && (size_t)fr * h < total_rows;
+        c.row = (size_t)(c.valid ? fr : 0) * h + (c.valid ? rb : 0);
+        if (!c.valid) {
+            c.f = 0;
+            c.y = 0;
+        }
+    }
     const int wv = threadIdx.x >> 6;
     const uint32_t *row = bits + (c.valid ? c.row : 0) * w32;
     int32_t *L = labels + (size_t)c.f * h * w;
@@ -1602,19 +1619,23 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     if (!paint)
         return VA_OK;
     const int vec = (w % 4 == 0) && aligned(labels, 16);
+    // frames follow the XCD of their labelling workgroup when the per-frame kernel ran (see the kernel)
+    const int bpf = cdiv(h, kRowsPerBlock);
+    const int xcd_frames = table_mode ? bpf : 0;
+    const int pgrid = xcd_frames ? 8 * bpf * cdiv(n, 8) : grid;
     if (stats && max_labels > 0) {
         size_t entries = (size_t)n * max_labels;
         stats_init_kernel<<<cdiv((long long)entries * VA_STATS_STRIDE, kBlock), kBlock, 0, st>>>(
             stats, entries, h, w);
         VA_LAUNCH_CHECK("stats_init_kernel");
         VA_MARK("stats_init");
-        ccl_paint_kernel<true><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows, stats,
-                                                       max_labels, vec, table_mode ? run_table : nullptr,
-                                                       table_stride, row_off, frame_mode);
+        ccl_paint_kernel<true><<<pgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows, stats,
+                                                        max_labels, vec, table_mode ? run_table : nullptr,
+                                                        table_stride, row_off, frame_mode, xcd_frames);
     } else {
-        ccl_paint_kernel<false><<<grid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows,
-                                                        nullptr, 0, vec, table_mode ? run_table : nullptr,
-                                                        table_stride, row_off, frame_mode);
+        ccl_paint_kernel<false><<<pgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows,
+                                                         nullptr, 0, vec, table_mode ? run_table : nullptr,
+                                                         table_stride, row_off, frame_mode, xcd_frames);
     }
     VA_LAUNCH_CHECK("ccl_paint_kernel");
     VA_MARK("ccl_paint");
