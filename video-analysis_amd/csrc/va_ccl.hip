@@ -515,7 +515,7 @@ constexpr int kChunk = 8;                                         // words per l
 constexpr int kStagePad = 4;                                      // zero words left of a staged row
 
 struct FrameLayout {   // word offsets into the kernel's LDS array
-    int row_stride;    // staged row: kStagePad zeros, the row, zeros up to 8 lanes x chunks + 4
+    int row_stride;    // staged row: kStagePad zeros, the row, zeros up to 8 lanes x chunks + 4; ODD (see frame_layout)
     int stage_words;   // per wave: 9 staged rows of the mask
     int queue_off, rowbase_off, parent_off, lds_runs;
 };
@@ -528,7 +528,11 @@ inline int span_chunks(int w32, int rpw)
 inline FrameLayout frame_layout(int h, int w32, int rpw)
 {
     FrameLayout l;
-    l.row_stride = kStagePad + (kWave / rpw) * span_chunks(w32, rpw) * kChunk + 4;
+    // odd stride: a lane reads the same word k of ITS span (8-word stride within a row) in every step, so
+    // the rows a half-wave covers must fall on different banks mod 8 (a stride that is a multiple of 4,
+    // as 16-byte stage writes would need, puts 32 lanes on 4 banks: SQ_LDS_BANK_CONFLICT was 55 % of
+    // the kernel's LDS cycles)
+    l.row_stride = (kStagePad + (kWave / rpw) * span_chunks(w32, rpw) * kChunk + 4) | 1;
     l.stage_words = (rpw + 1) * l.row_stride;
     l.queue_off = kFrameWaves * l.stage_words;
     l.rowbase_off = l.queue_off + kFrameWaves * 2 * kQueue;
@@ -690,10 +694,18 @@ __device__ __forceinline__ void scan_rows(int *rowbase, int h, int *s_part, int 
 // The paint pass numbers the runs of its row the same way (row base + run starts to the left) and
 // needs ONE cached load per run.  Frames in large-frame mode keep the sparse convention (mode 0);
 // so does the contour tracer, which reads roots at first pixels (table == nullptr).
+#ifdef VA_CCL_STAMPS
+__device__ long long g_ccl_stamps[16];
+#define CCL_ACC(v, t0) do { long long t1_ = __builtin_amdgcn_s_memtime(); v += t1_ - t0; t0 = t1_; } while (0)
+#define CCL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ccl_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CCL_STAMP(i) do { } while (0)
+#define CCL_ACC(v, t0) do { } while (0)
+#endif
 template <bool CONN8, int NCH, int RPW>
 __global__ void __launch_bounds__(kFrameThreads)
 ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
-                 int32_t *__restrict__ counts, int h, int w, int w32, FrameLayout lay, int vec,
+                 int32_t *__restrict__ counts, int h, int w, int w32, FrameLayout lay,
                  int32_t *__restrict__ table, int table_stride, int32_t *__restrict__ rowbase_g,
                  int32_t *__restrict__ mode)
 {
@@ -715,46 +727,42 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     const int sweeps = (h + kRowsPerIter - 1) / kRowsPerIter;
 
     // stage image rows y0 - 1 ... y0 + 7 of this wave's sweep step (slot 0 is the row above y0).
-    // All nine loads are issued before any is used -- one memory round trip per sweep step --
+    // All loads are issued before any is used -- one memory round trip per sweep step --
     // from clamped, always valid addresses: slots of rows outside the frame hold a copy of an
     // edge row, and no lane that reads them is `valid`.
     typedef int v4i __attribute__((ext_vector_type(4)));
     struct RowRegs {
-        v4i v[RPW + 1];   // 16 bytes of each row (vec) or words lane, lane + 64 in .x, .y
+        v4i v[RPW + 1];   // words lane, lane + 64, lane + 128, lane + 192 of each row (w32 <= 256)
     };
+    const int nld = (w32 + kWave - 1) / kWave;       // word loads per row (wave-uniform)
     auto issue_rows = [&](int y0, RowRegs &rr) {
-        if (vec) {
-            const int col = min(lane * 4, w32 - 4);
+        const int c0 = min(lane, w32 - 1), c1 = min(lane + kWave, w32 - 1);
+        const int c2 = min(lane + 2 * kWave, w32 - 1), c3 = min(lane + 3 * kWave, w32 - 1);
 #pragma unroll
-            for (int j = 0; j <= RPW; j++) {
-                const int y = min(max(y0 - 1 + j, 0), h - 1);
-                rr.v[j] = *reinterpret_cast<const v4i *>(fbits + (size_t)y * w32 + col);
-            }
-        } else {
-            const int c0 = min(lane, w32 - 1), c1 = min(lane + kWave, w32 - 1);   // w32 <= 128
-#pragma unroll
-            for (int j = 0; j <= RPW; j++) {
-                const uint32_t *src = fbits + (size_t)min(max(y0 - 1 + j, 0), h - 1) * w32;
-                rr.v[j].x = (int)src[c0];
+        for (int j = 0; j <= RPW; j++) {
+            const uint32_t *src = fbits + (size_t)min(max(y0 - 1 + j, 0), h - 1) * w32;
+            rr.v[j].x = (int)src[c0];
+            if (nld > 1)
                 rr.v[j].y = (int)src[c1];
+            if (nld > 2) {
+                rr.v[j].z = (int)src[c2];
+                rr.v[j].w = (int)src[c3];
             }
         }
     };
     auto commit_rows = [&](const RowRegs &rr) {
         wave_sync();                                    // earlier readers of the stage are done
-        if (vec) {
-            if (lane * 4 < w32) {
 #pragma unroll
-                for (int j = 0; j <= RPW; j++)
-                    *reinterpret_cast<v4i *>(stage + j * rs + lane * 4) = rr.v[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j <= RPW; j++) {
-                if (lane < w32)
-                    stage[j * rs + lane] = rr.v[j].x;
-                if (lane + kWave < w32)
-                    stage[j * rs + lane + kWave] = rr.v[j].y;
+        for (int j = 0; j <= RPW; j++) {
+            if (lane < w32)
+                stage[j * rs + lane] = rr.v[j].x;
+            if (nld > 1 && lane + kWave < w32)
+                stage[j * rs + lane + kWave] = rr.v[j].y;
+            if (nld > 2) {
+                if (lane + 2 * kWave < w32)
+                    stage[j * rs + lane + 2 * kWave] = rr.v[j].z;
+                if (lane + 3 * kWave < w32)
+                    stage[j * rs + lane + 3 * kWave] = rr.v[j].w;
             }
         }
         wave_sync();
@@ -762,6 +770,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     // ---- 1. runs per row, exclusive scan -> first run id of every row -----------------------
     // (the next step's rows are in flight while this step's are counted: one memory round trip
     // per sweep step would otherwise be exposed 2 x 8.4 times per frame)
+    CCL_STAMP(0);
     RowRegs rr1;
     issue_rows(wv * RPW, rr1);
     for (int it = 0; it < sweeps; it++) {
@@ -777,8 +786,10 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
             rowbase[c.y] = n;
     }
     __syncthreads();
+    CCL_STAMP(1);
     scan_rows(rowbase, h, s_part, &s_total);
     const int nruns = s_total;
+    CCL_STAMP(2);
 
     if (table && tid == 0)
         mode[f] = nruns <= lay.lds_runs ? 1 : 0;
@@ -835,11 +846,14 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     };
 
     // ---- 3. link runs of row y with runs of row y-1 -----------------------------------------------
+    CCL_STAMP(3);
     RowRegs rr3;
     issue_rows(wv * RPW, rr3);
+    long long a_commit = 0, a_count = 0, a_pairs = 0, a_drain = 0, a_t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < sweeps; it++) {
         const int y0 = it * kRowsPerIter + wv * RPW;
         commit_rows(rr3);
+        CCL_ACC(a_commit, a_t0);
         issue_rows(y0 + kRowsPerIter, rr3);
         const FrameSpan c = frame_span<NCH, RPW>(y0, h, w32);
         const bool act = c.valid && c.y > 0;
@@ -870,6 +884,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         }
         int nq_total;
         int slot = wave_prefix(ncontacts, &nq_total);
+        CCL_ACC(a_count, a_t0);
         if (act) {
             cc += rowbase[c.y] - 1;        // id of the run that holds pixel x = cc + starts in the
             cu += rowbase[c.y - 1] - 1;    // span at or left of x (same for the row above)
@@ -921,11 +936,19 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         }
         // drain: every lane takes queued contacts, so the wave runs one union chain deep
         wave_sync();
+        CCL_ACC(a_pairs, a_t0);
         const int nq = min(nq_total, kQueue);
         for (int i = lane; i < nq; i += kWave)
             lds_unite(parent, queue[2 * i], queue[2 * i + 1]);
+        CCL_ACC(a_drain, a_t0);
     }
+#ifdef VA_CCL_STAMPS
+    if (blockIdx.x == 0 && tid == 0) {
+        g_ccl_stamps[8] = a_commit; g_ccl_stamps[9] = a_count; g_ccl_stamps[10] = a_pairs; g_ccl_stamps[11] = a_drain;
+    }
+#endif
     __syncthreads();
+    CCL_STAMP(4);
 
     // ---- 4. flatten, rank the roots in id (= raster) order -----------------------------------------
     const int ids_per_thread = (nruns + kFrameThreads - 1) / kFrameThreads;
@@ -946,6 +969,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         if (parent[i] == i)
             parent[i] = -(++k);            // roots: -(label); only this thread touches entry i
     __syncthreads();
+    CCL_STAMP(5);
 
     if (table) {
         // ---- 5a. the labels leave as a table (coalesced), with the first run id of every row --------
@@ -959,6 +983,8 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         int32_t *rb = rowbase_g + (size_t)f * h;
         for (int y = tid; y < h; y += kFrameThreads)
             rb[y] = rowbase[y];
+        __syncthreads();
+        CCL_STAMP(6);
         return;
     }
     // ---- 5. one sparse write per run: what the paint pass and the contour tracer read ---------------
@@ -1591,12 +1617,11 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
         FrameLayout lay = frame_layout(h, w32, rpw);
         if (g_ccl_lds_runs > 0)                            // test hook: force the large-frame mode
             lay.lds_runs = min(lay.lds_runs, g_ccl_lds_runs);
-        const int vec = (w32 % 4 == 0) && aligned(bits, 16);
         const int nch = span_chunks(w32, rpw);
         table_mode = paint && !g_ccl_sparse; // (the contour tracer reads roots in the label image instead)
         table_stride = lay.lds_runs;
 #define VA_FRAME_LAUNCH(C8, NCH, RPW)                                                                       \
-    ccl_frame_kernel<C8, NCH, RPW><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, vec,  \
+    ccl_frame_kernel<C8, NCH, RPW><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay,  \
                                                                  table_mode ? run_table : nullptr, lay.lds_runs, \
                                                                  row_off, frame_mode)
 #define VA_FRAME_CASE(NCH, RPW)                 \
@@ -1705,3 +1730,10 @@ int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, i
     return VA_OK;
 }
 }  // namespace va
+
+#ifdef VA_CCL_STAMPS
+extern "C" int va_debug_ccl_stamps(long long *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(va::g_ccl_stamps), sizeof(long long) * 16);
+}
+#endif
