@@ -340,7 +340,8 @@ int va_morph_bits_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int
  * chip-wide passes: frames up to 1080p in batches of about 16 frames or more, 4K frames from
  * about 64, small frames in any batch; chip-wide passes otherwise), 1 = chip-wide passes, 2 = per-frame kernel,
  * 3 = the library's choice, but the per-frame kernel hands its labels to the paint pass as sparse words in the
- * label image (round 1's convention) instead of compact run tables;
+ * label image (round 1's convention) instead of compact run tables; 4 = the per-frame kernel (as 2),
+ * staging the mask rows in LDS even where it could read its spans straight from global memory;
  * lds_runs > 0 caps the per-frame kernel's run table (frames above it take its large-frame mode) */
 int va_test_hook_labelling(int path, int lds_runs);
 

@@ -291,14 +291,16 @@ def test_morphology_golden_and_oracle(ops, golden, oracle):
 
 
 # --------------------------------------------------------------------------- labelling
-@pytest.fixture(params=["frame-lds", "frame-large", "chip-wide"])
+@pytest.fixture(params=["frame-lds", "frame-staged", "frame-large", "chip-wide"])
 def ccl_mode(request):
-    """the three labelling code paths of launch_ccl (va_ccl.hip), selected through the library's
-    test hooks: one workgroup per frame with the forest in LDS (the default for large batches), the same kernel's
+    """the labelling code paths of launch_ccl (va_ccl.hip), selected through the library's test hooks: one
+    workgroup per frame with the forest in LDS (the default for large batches; spans read straight from
+    global memory where rows are 16-byte aligned), the same with every row staged in LDS, the same kernel's
     large-frame mode (forest in the label image; forced by a tiny LDS budget), and the chip-wide
     multi-pass path that frames taller than the LDS row table take"""
     # (without a hook the library picks by a cost model of frame size and batch size)
-    path, lds_runs = {"frame-lds": (2, 0), "frame-large": (2, 7), "chip-wide": (1, 0)}[request.param]
+    path, lds_runs = {"frame-lds": (2, 0), "frame-staged": (4, 0), "frame-large": (2, 7),
+                      "chip-wide": (1, 0)}[request.param]
     from video import _hip
     _hip.check(_hip.lib().va_test_hook_labelling(path, lds_runs))
     yield request.param
@@ -322,7 +324,9 @@ def test_label_golden_scipy_vectors(ops, golden, ccl_mode):
                                                (31, 2100, 0.5, 5), (300, 65, 0.7, 6),
                                                (128, 4160, 0.59, 7), (1, 500, 0.5, 8),
                                                (500, 1, 0.5, 9), (70, 3840, 0.5, 10),
-                                               (45, 2500, 0.62, 11)])
+                                               (45, 2500, 0.62, 11), (100, 1920, 0.55, 12),
+                                               (64, 128, 0.5, 13), (50, 256, 0.6, 14),
+                                               (1080, 1920, 0.02, 15)])
 def test_label_random_vs_oracle(ops, oracle, h, w, density, seed, ccl_mode):
     rng = np.random.default_rng(seed)
     m = (rng.random((3, h, w)) < density).astype(np.uint8)

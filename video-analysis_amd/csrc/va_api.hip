@@ -403,7 +403,7 @@ int va_gaussian_u8_valu(const uint8_t *src, uint8_t *dst, int n, int h, int w, i
 // test hook: pin the labelling code path of every later call in this process
 int va_test_hook_labelling(int path, int lds_runs)
 {
-    VA_REQUIRE(path >= 0 && path <= 3 && lds_runs >= 0, "va_test_hook_labelling: bad arguments");
+    VA_REQUIRE(path >= 0 && path <= 4 && lds_runs >= 0, "va_test_hook_labelling: bad arguments");
     ccl_test_hook(path, lds_runs);
     return VA_OK;
 }

@@ -352,6 +352,25 @@ __device__ __forceinline__ int row_prefix(int v, int lane)
     return incl - v;
 }
 
+// inclusive prefix over contiguous groups of G lanes (G = 8 or 16; g = lane % G): DPP row shifts, no
+// LDS crossbar round trips (the strided row_prefix above pays three dependent ones)
+template <int G>
+__device__ __forceinline__ int seg_inclusive(int v, int g)
+{
+    int x = v, t;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    x += g >= 1 ? t : 0;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    x += g >= 2 ? t : 0;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    x += g >= 4 ? t : 0;
+    if (G > 8) {
+        t = __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+        x += g >= 8 ? t : 0;
+    }
+    return x;
+}
+
 // exclusive prefix over the 64 lanes of the wave (DPP: Hillis-Steele inside the rows of 16, then
 // the two row broadcasts); *total = sum over the wave
 __device__ __forceinline__ int wave_prefix(int v, int *total)
@@ -705,7 +724,7 @@ __device__ long long g_ccl_stamps[16];
 template <bool CONN8, int NCH, int RPW>
 __global__ void __launch_bounds__(kFrameThreads)
 ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels,
-                 int32_t *__restrict__ counts, int h, int w, int w32, FrameLayout lay,
+                 int32_t *__restrict__ counts, int h, int w, int w32, FrameLayout lay, int direct,
                  int32_t *__restrict__ table, int table_stride, int32_t *__restrict__ rowbase_g,
                  int32_t *__restrict__ mode)
 {
@@ -771,6 +790,48 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     // (the next step's rows are in flight while this step's are counted: one memory round trip
     // per sweep step would otherwise be exposed 2 x 8.4 times per frame)
     CCL_STAMP(0);
+    // Direct form (NCH == 1, rows 16-byte aligned): the lanes of a row are CONTIGUOUS (r = lane / G,
+    // g = lane % G), each loads its 8-word span with two 16-byte loads -- no LDS stage, no stage
+    // synchronisation; the word left/right of the span comes from the neighbour lane (DPP) and the
+    // per-row prefix is a DPP scan over G lanes.
+    constexpr int G = kWave / RPW;
+    const int dr = lane / G, dg = lane % G;
+    struct SpanRegs {
+        v4i a, b;
+    };
+    auto load_direct = [&](int y, SpanRegs &sp) {    // zero outside the frame and past the row's end
+        sp.a = v4i{0, 0, 0, 0};
+        sp.b = v4i{0, 0, 0, 0};
+        if (y >= 0 && y < h) {
+            const uint32_t *src = fbits + (size_t)y * w32 + 8 * dg;
+            if (8 * dg + 4 <= w32)
+                sp.a = *reinterpret_cast<const v4i *>(src);
+            if (8 * dg + 8 <= w32)
+                sp.b = *reinterpret_cast<const v4i *>(src + 4);
+        }
+    };
+    auto expand = [&](const SpanRegs &sp, uint32_t (&m)[NCH][kChunk + 2]) {
+        m[0][1] = sp.a.x, m[0][2] = sp.a.y, m[0][3] = sp.a.z, m[0][4] = sp.a.w;
+        m[0][5] = sp.b.x, m[0][6] = sp.b.y, m[0][7] = sp.b.z, m[0][8] = sp.b.w;
+        const uint32_t left = __builtin_amdgcn_update_dpp(0u, m[0][8], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+        const uint32_t right = __builtin_amdgcn_update_dpp(0u, m[0][1], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        m[0][0] = dg > 0 ? left : 0u;
+        m[0][9] = dg < G - 1 ? right : 0u;
+    };
+    if (NCH == 1 && direct) {
+        SpanRegs pre;
+        load_direct(wv * RPW + dr, pre);
+        for (int it = 0; it < sweeps; it++) {      // (deeper prefetch changes nothing: the sweep is issue-bound)
+            const int y = it * kRowsPerIter + wv * RPW + dr;
+            const SpanRegs cur = pre;
+            load_direct(y + kRowsPerIter, pre);
+            uint32_t mw[NCH][kChunk + 2];
+            expand(cur, mw);
+            const int n = seg_inclusive<G>(count_starts<NCH>(mw), dg);
+            if (dg == G - 1 && y < h)
+                rowbase[y] = n;
+        }
+    } else {
     RowRegs rr1;
     issue_rows(wv * RPW, rr1);
     for (int it = 0; it < sweeps; it++) {
@@ -784,6 +845,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         n = row_sum<RPW>(n);
         if (lane < RPW && c.y < h)
             rowbase[c.y] = n;
+    }
     }
     __syncthreads();
     CCL_STAMP(1);
@@ -846,24 +908,13 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     };
 
     // ---- 3. link runs of row y with runs of row y-1 -----------------------------------------------
-    CCL_STAMP(3);
-    RowRegs rr3;
-    issue_rows(wv * RPW, rr3);
+#ifdef VA_CCL_STAMPS
     long long a_commit = 0, a_count = 0, a_pairs = 0, a_drain = 0, a_t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < sweeps; it++) {
-        const int y0 = it * kRowsPerIter + wv * RPW;
-        commit_rows(rr3);
-        CCL_ACC(a_commit, a_t0);
-        issue_rows(y0 + kRowsPerIter, rr3);
-        const FrameSpan c = frame_span<NCH, RPW>(y0, h, w32);
-        const bool act = c.valid && c.y > 0;
-        uint32_t mw[NCH][kChunk + 2], uw[NCH][kChunk + 2];
-        load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
-        load_span<NCH>(stage + c.r * rs, c.w0, uw);
-        const int nc = act ? count_starts<NCH>(mw) : 0;
-        const int nu = act ? count_starts<NCH>(uw) : 0;
-        // runs of the row that start left of this lane's span
-        int cc = row_prefix<RPW>(nc, lane), cu = row_prefix<RPW>(nu, lane);
+#endif
+    // contacts of one sweep step: mw / uw = this lane's span of row y and of row y - 1, cc / cu = runs of
+    // those rows that start left of the span
+    auto link_rows = [&](bool act, int y, const uint32_t (&mw)[NCH][kChunk + 2],
+                         const uint32_t (&uw)[NCH][kChunk + 2], int cc, int cu) {
         // contacts of this lane's span (the same bit tricks as below, counted)
         int ncontacts = 0;
         if (act) {
@@ -886,8 +937,8 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         int slot = wave_prefix(ncontacts, &nq_total);
         CCL_ACC(a_count, a_t0);
         if (act) {
-            cc += rowbase[c.y] - 1;        // id of the run that holds pixel x = cc + starts in the
-            cu += rowbase[c.y - 1] - 1;    // span at or left of x (same for the row above)
+            cc += rowbase[y] - 1;        // id of the run that holds pixel x = cc + starts in the
+            cu += rowbase[y - 1] - 1;    // span at or left of x (same for the row above)
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
 #pragma unroll
@@ -940,7 +991,45 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         const int nq = min(nq_total, kQueue);
         for (int i = lane; i < nq; i += kWave)
             lds_unite(parent, queue[2 * i], queue[2 * i + 1]);
+    };
+    CCL_STAMP(3);
+    if (NCH == 1 && direct) {
+        SpanRegs pre, pre_up;
+        load_direct(wv * RPW + dr, pre);
+        load_direct(wv * RPW + dr - 1, pre_up);
+        for (int it = 0; it < sweeps; it++) {
+            const int y = it * kRowsPerIter + wv * RPW + dr;
+            const SpanRegs cur = pre, up = pre_up;
+            load_direct(y + kRowsPerIter, pre);
+            load_direct(y + kRowsPerIter - 1, pre_up);
+            const bool act = y < h && y > 0;
+            uint32_t mw[NCH][kChunk + 2], uw[NCH][kChunk + 2];
+            expand(cur, mw);
+            expand(up, uw);
+            const int nc = act ? count_starts<NCH>(mw) : 0;
+            const int nu = act ? count_starts<NCH>(uw) : 0;
+            link_rows(act, y, mw, uw, seg_inclusive<G>(nc, dg) - nc, seg_inclusive<G>(nu, dg) - nu);
+        }
+    } else {
+    RowRegs rr3;
+    issue_rows(wv * RPW, rr3);
+    for (int it = 0; it < sweeps; it++) {
+        const int y0 = it * kRowsPerIter + wv * RPW;
+        commit_rows(rr3);
+        CCL_ACC(a_commit, a_t0);
+        issue_rows(y0 + kRowsPerIter, rr3);
+        const FrameSpan c = frame_span<NCH, RPW>(y0, h, w32);
+        const bool act = c.valid && c.y > 0;
+        uint32_t mw[NCH][kChunk + 2], uw[NCH][kChunk + 2];
+        load_span<NCH>(stage + (c.r + 1) * rs, c.w0, mw);
+        load_span<NCH>(stage + c.r * rs, c.w0, uw);
+        const int nc = act ? count_starts<NCH>(mw) : 0;
+        const int nu = act ? count_starts<NCH>(uw) : 0;
+        // runs of the row that start left of this lane's span
+        int cc = row_prefix<RPW>(nc, lane), cu = row_prefix<RPW>(nu, lane);
+        link_rows(act, c.y, mw, uw, cc, cu);
         CCL_ACC(a_drain, a_t0);
+    }
     }
 #ifdef VA_CCL_STAMPS
     if (blockIdx.x == 0 && tid == 0) {
@@ -1499,10 +1588,13 @@ static int g_ccl_path = 0;
 static int g_ccl_lds_runs = 0;
 static int g_ccl_sparse = 0;   // hook path 3: the library's choice of kernel, labels handed to the paint
                                // pass as sparse words in the label image (the round-1 convention)
+static int g_ccl_no_direct = 0; // hook path 4: the per-frame kernel (as path 2), staging its rows in LDS even
+                               // where it could read its spans straight from global memory
 void ccl_test_hook(int path, int lds_runs)
 {
     g_ccl_sparse = path == 3;
-    g_ccl_path = path == 3 ? 0 : path;
+    g_ccl_no_direct = path == 4;
+    g_ccl_path = path == 4 ? 2 : path == 3 ? 0 : path;
     g_ccl_lds_runs = lds_runs;
 }
 
@@ -1618,10 +1710,12 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
         if (g_ccl_lds_runs > 0)                            // test hook: force the large-frame mode
             lay.lds_runs = min(lay.lds_runs, g_ccl_lds_runs);
         const int nch = span_chunks(w32, rpw);
+        // spans straight from 16-byte global loads (no LDS stage) where rows are 16-byte aligned
+        const int direct = nch == 1 && (w32 % 4 == 0) && aligned(bits, 16) && !g_ccl_no_direct;
         table_mode = paint && !g_ccl_sparse; // (the contour tracer reads roots in the label image instead)
         table_stride = lay.lds_runs;
 #define VA_FRAME_LAUNCH(C8, NCH, RPW)                                                                       \
-    ccl_frame_kernel<C8, NCH, RPW><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay,  \
+    ccl_frame_kernel<C8, NCH, RPW><<<n, kFrameThreads, 0, st>>>(bits, labels, counts, h, w, w32, lay, direct,  \
                                                                  table_mode ? run_table : nullptr, lay.lds_runs, \
                                                                  row_off, frame_mode)
 #define VA_FRAME_CASE(NCH, RPW)                 \
