@@ -737,8 +737,10 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     int32_t *L = labels + (size_t)f * h * w;
     int *stage = s_mem + wv * lay.stage_words + kStagePad;   // slot j <-> image row y0 - 1 + j
     const int rs = lay.row_stride;
-    for (int i = lane; i < lay.stage_words; i += kWave)       // the pads stay zero for good
-        stage[i - kStagePad] = 0;
+    const bool spans_direct = NCH == 1 && direct;              // sweeps 1 and 3 read global memory (below)
+    if (!spans_direct)
+        for (int i = lane; i < lay.stage_words; i += kWave)   // the pads stay zero for good
+            stage[i - kStagePad] = 0;
     int *queue = s_mem + lay.queue_off + wv * 2 * kQueue;
     int *rowbase = s_mem + lay.rowbase_off;
     int *parent = s_mem + lay.parent_off;
@@ -818,7 +820,11 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         m[0][0] = dg > 0 ? left : 0u;
         m[0][9] = dg < G - 1 ? right : 0u;
     };
-    if (NCH == 1 && direct) {
+    // the row stages are unused in this form: where they are large enough they keep every span's
+    // prefix (run starts of its row to the left) from the first sweep for the second
+    int *pref = s_mem;
+    const bool keep_pref = h * G <= lay.queue_off;
+    if (spans_direct) {
         SpanRegs pre;
         load_direct(wv * RPW + dr, pre);
         for (int it = 0; it < sweeps; it++) {      // (deeper prefetch changes nothing: the sweep is issue-bound)
@@ -827,9 +833,12 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
             load_direct(y + kRowsPerIter, pre);
             uint32_t mw[NCH][kChunk + 2];
             expand(cur, mw);
-            const int n = seg_inclusive<G>(count_starts<NCH>(mw), dg);
+            const int own = count_starts<NCH>(mw);
+            const int n = seg_inclusive<G>(own, dg);
             if (dg == G - 1 && y < h)
                 rowbase[y] = n;
+            if (keep_pref && y < h)
+                pref[y * G + dg] = n - own;
         }
     } else {
     RowRegs rr1;
@@ -936,6 +945,8 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         int nq_total;
         int slot = wave_prefix(ncontacts, &nq_total);
         CCL_ACC(a_count, a_t0);
+        if (nq_total == 0)                 // wave-uniform: nothing touches the rows above in this step
+            return;
         if (act) {
             cc += rowbase[y] - 1;        // id of the run that holds pixel x = cc + starts in the
             cu += rowbase[y - 1] - 1;    // span at or left of x (same for the row above)
@@ -993,7 +1004,7 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
             lds_unite(parent, queue[2 * i], queue[2 * i + 1]);
     };
     CCL_STAMP(3);
-    if (NCH == 1 && direct) {
+    if (spans_direct) {
         SpanRegs pre, pre_up;
         load_direct(wv * RPW + dr, pre);
         load_direct(wv * RPW + dr - 1, pre_up);
@@ -1006,9 +1017,19 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
             uint32_t mw[NCH][kChunk + 2], uw[NCH][kChunk + 2];
             expand(cur, mw);
             expand(up, uw);
-            const int nc = act ? count_starts<NCH>(mw) : 0;
-            const int nu = act ? count_starts<NCH>(uw) : 0;
-            link_rows(act, y, mw, uw, seg_inclusive<G>(nc, dg) - nc, seg_inclusive<G>(nu, dg) - nu);
+            int cc = 0, cu = 0;
+            if (keep_pref) {
+                if (act) {
+                    cc = pref[y * G + dg];
+                    cu = pref[(y - 1) * G + dg];
+                }
+            } else {
+                const int nc = act ? count_starts<NCH>(mw) : 0;
+                const int nu = act ? count_starts<NCH>(uw) : 0;
+                cc = seg_inclusive<G>(nc, dg) - nc;
+                cu = seg_inclusive<G>(nu, dg) - nu;
+            }
+            link_rows(act, y, mw, uw, cc, cu);
         }
     } else {
     RowRegs rr3;
@@ -1087,6 +1108,9 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
             v = -((-parent[v]) | kNonRootBit);
         return v;
     };
+    if (spans_direct)                                          // the stages held span prefixes until now
+        for (int i = lane; i < lay.stage_words; i += kWave)
+            stage[i - kStagePad] = 0;
     RowRegs rr;
     issue_rows(wv * RPW, rr);
     for (int it = 0; it < sweeps; it++) {
