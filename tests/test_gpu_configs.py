@@ -224,6 +224,31 @@ def test_stress_slice_gaussian_f32(oracle):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (shape, sigma)
 
 
+def test_gaussian_f32_column_kernels(oracle):
+    """the unrolled 15/16-rows-per-thread column kernels (radii of integer sigmas) against the oracle and
+    against the runtime-radius kernel (test hook), over heights around their 120/128-row steps"""
+    from video import ops, _hip
+    rng = np.random.default_rng(77)
+    shapes = [(120, 64), (121, 68), (128, 200), (129, 64), (240, 96), (241, 132), (257, 64), (384, 68),
+              (1, 64), (2, 72), (37, 64), (500, 36)]
+    for h, w in shapes:
+        for sigma in (1.0, 2.0, 3.0, 5.0, 7.0, 9.0):
+            c = 3 if (h + int(sigma)) % 3 == 0 else 1
+            shape = (2, h, w, 3) if c == 3 else (2, h, w)
+            f = (rng.random(shape, dtype=np.float32) * 3 - 1).astype(np.float32)
+            f.flat[::41] = 0.0
+            f.flat[5::97] = -0.0
+            ref = oracle.gaussian_f32(f, sigma)
+            got = ops.gaussian_blur(f, sigma, color=(c == 3))
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (shape, sigma)
+            _hip.check(_hip.lib().va_test_hook_gaussian_f32(1))
+            try:
+                gen = ops.gaussian_blur(f, sigma, color=(c == 3))
+            finally:
+                _hip.check(_hip.lib().va_test_hook_gaussian_f32(0))
+            assert np.array_equal(gen.view(np.uint32), ref.view(np.uint32)), (shape, sigma, "generic")
+
+
 def test_stress_slice_round2_paths(oracle):
     """a bounded, seeded slice of tools/stress_misc.py: float32 EMA + blur through the pipeline at random
     shapes with split batches, cv2.resize in every mode, contour moments of traced contours"""

@@ -408,6 +408,12 @@ int va_test_hook_labelling(int path, int lds_runs)
     return VA_OK;
 }
 
+int va_test_hook_gaussian_f32(int generic_columns)
+{
+    gauss_f32_test_hook(generic_columns);
+    return VA_OK;
+}
+
 int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, double sigma,
                     void *stream)
 {

@@ -106,6 +106,7 @@ int launch_gauss_f32_fast(const float *src, float *dst, float *scratch, int n, i
                           const TapsF32 &taps, hipStream_t st);
 // float32 path in two kernels (va_gauss_f32_fused.hip): [EMA background + |difference| + row pass]
 // with the background state in registers, then a marching column pass.  bg == nullptr: plain blur.
+void gauss_f32_test_hook(int generic_columns);
 bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps);
 int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *bg, int64_t n_seen,
                            double rate, int n, int h, int w, int c, const TapsF32 &taps, hipStream_t st,

@@ -36,6 +36,8 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -722,6 +724,242 @@ col_march_f32_kernel(const float *__restrict__ tmp, float *__restrict__ dst, int
     }
 }
 
+
+// ---- column pass, radius known at compile time ----------------------------------------------------
+// Same march as col_march_f32_kernel, for the radii integer sigmas give (r = 4 sigma): with the tap
+// loop fully unrolled every ring slot is static, so a thread keeps R = 15 or 16 output rows (not 8)
+// in three plain register arrays -- rows above, rows below, accumulators -- without role swaps or
+// moves: R + 2r LDS reads feed R (2r + 1) packed operations (1 : 13 for sigma 9; the 8-row form
+// reads 1 : 7 and kept the LDS pipe of a CU 77 % busy), and a step covers 8 R rows, so the 2r-row
+// slide is paid half as often.  R = 15 makes 1080 rows nine whole steps.
+template <int RAD, int R>
+__global__ void __launch_bounds__(256, 3)
+col_sym_f32_kernel(const float *__restrict__ tmp, float *__restrict__ dst, int h, int rw, int ncolt,
+                   TapsF32 taps)
+{
+    constexpr int ROWS = 8 * R;                          // output rows per step
+    constexpr int NROWS = ROWS + 2 * RAD;                // tile rows; row j <-> image row y0 - RAD + j
+    constexpr int RS = kColCols / 2;                     // row stride in f2 (no pad: f2 reads of a
+                                                         // half-wave cover one whole row)
+    extern __shared__ float tile[];
+    const int tid = threadIdx.x;
+    const int ct = blockIdx.x % ncolt;
+    const size_t fz = blockIdx.x / ncolt;
+    const int x0 = ct * kColCols;
+    const float *frame = tmp + fz * (size_t)h * rw;
+    float *oframe = dst + fz * (size_t)h * rw;
+
+    const int period = h > 1 ? 2 * (h - 1) : 1;
+    auto reflect_row = [&](int yin) -> int {             // BORDER_REFLECT_101 (see col_march_f32_kernel)
+        int y = yin < 0 ? -yin : yin;
+        y = y >= h ? period - y : y;
+        if (__builtin_expect(y < 0 || y >= h, 0)) {
+            int m = yin % period;
+            m = m < 0 ? m + period : m;
+            y = m < h ? m : period - m;
+        }
+        return y;
+    };
+    auto load4 = [&](int y, int c4) -> f4 {
+        const float *g = frame + (size_t)reflect_row(y) * rw + min(x0 + c4, rw - 4);
+        return __builtin_nontemporal_load(reinterpret_cast<const f4 *>(g));
+    };
+    auto put4 = [&](int row, int c4, f4 v) {
+        float *d = tile + row * kColCols + c4;
+        *reinterpret_cast<f2 *>(d) = f2{v.x, v.y};
+        *reinterpret_cast<f2 *>(d + 2) = f2{v.z, v.w};
+    };
+
+    {   // first tile: rows -RAD .. ROWS + RAD - 1
+        constexpr int items = NROWS * (kColCols / 4);
+#pragma unroll 1
+        for (int base = 0; base < items; base += 4 * 256) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = min(base + u * 256 + tid, items - 1);
+                v[u] = load4(-RAD + (idx >> 4), (idx & 15) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + u * 256 + tid;
+                if (idx < items)
+                    put4(idx >> 4, (idx & 15) * 4, v[u]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int cp = tid & 31, rg = tid >> 5;
+    const int col = x0 + 2 * cp;
+    constexpr int NPF = (ROWS * (kColCols / 4) + 255) / 256;      // float4 per thread and step
+    constexpr int NMV = (2 * RAD * RS + 255) / 256;               // f2 per thread in the slide
+
+    for (int y0 = 0; y0 < h; y0 += ROWS) {
+        // (the tile addresses do not depend on y0: hidden from the optimiser, which would otherwise
+        // keep all of them in registers across steps)
+        int toff = R * rg * RS + cp;
+        asm volatile("" : "+v"(toff));
+        const f2 *tlo = reinterpret_cast<const f2 *>(tile) + toff;  // tile row of image row c0 - RAD (c0: output j = 0)
+        int rw_o = rw;                                               // (as above: no per-row output offsets kept in
+        asm volatile("" : "+s"(rw_o));                               // registers across steps)
+        const bool more = y0 + ROWS < h;
+        // the next step's rows, in flight during the arithmetic (ts: the thread id, opaque per step -- else
+        // every staging index and address below is computed once and kept in registers for good)
+        int ts = tid;
+        asm volatile("" : "+v"(ts));
+        f4 pf[NPF];
+        constexpr int kEarly = NPF / 2;                    // loads issued before the arithmetic (registers
+        const bool plain = y0 + 2 * ROWS + RAD <= h;       // for all of them would cost the third workgroup
+        __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(   // of a CU), the rest after it
+            const_cast<float *>(frame) + (size_t)(y0 + ROWS + RAD) * rw_o, 0, ROWS * rw_o * 4, 0x00027000);
+        auto prefetch = [&](int u0, int u1) {
+            if (plain) {                                   // uniform: every row of the next step exists
+                const int c4 = min(x0 + (ts & 15) * 4, rw - 4);
+                const int voff = ((ts >> 4) * rw_o + c4) * 4;
+#pragma unroll
+                for (int u = u0; u < u1; u++) {            // (the last float4 of R = 15 steps: dropped below)
+                    const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(irsrc, voff, u * 16 * rw_o * 4, 2 /* nt */);
+                    pf[u] = __builtin_bit_cast(f4, raw);
+                }
+            } else {
+#pragma unroll
+                for (int u = u0; u < u1; u++) {
+                    const int idx = min(u * 256 + ts, ROWS * (kColCols / 4) - 1);
+                    pf[u] = load4(y0 + ROWS + RAD + (idx >> 4), (idx & 15) * 4);
+                }
+            }
+        };
+        if (more)
+            prefetch(0, kEarly);
+        if (col < rw) {
+            // centre tap, then symmetric pairs outwards (the oracle's order).  Ring slots: the row
+            // c0 + m (m may be negative) lives in slot m mod R of `up` resp. `dn`.
+            f2 up[R], dn[R], acc[R];
+            {
+                const f2 wc = f2{taps.t[RAD], taps.t[RAD]};
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    up[j] = dn[j] = tlo[(RAD + j) * RS];
+                    acc[j] = pk_fma(up[j], wc, f2{0.0f, 0.0f});
+                }
+            }
+            // the two rows a tap brings in are read kAheadTaps taps early; the scheduling fence after
+            // every tap keeps the compiler from hoisting ALL reads of the unrolled chain to its top
+            // (which spilled 58 registers)
+            constexpr int kAheadTaps = 3;
+            f2 su[kAheadTaps], sd[kAheadTaps];
+#pragma unroll
+            for (int k = 1; k <= kAheadTaps && k <= RAD; k++) {
+                su[k % kAheadTaps] = tlo[(RAD + R - 1 + k) * RS];
+                sd[k % kAheadTaps] = tlo[(RAD - k) * RS];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef COLSYM_NO_FMA
+            constexpr int kTapsRun = 2;
+#else
+            constexpr int kTapsRun = RAD;
+#endif
+#pragma unroll
+            for (int k = 1; k <= kTapsRun; k++) {
+                up[(R - 1 + k) % R] = su[k % kAheadTaps];                      // row c0 + R - 1 + k
+                dn[((-k) % R + R) % R] = sd[k % kAheadTaps];                   // row c0 - k
+                if (k + kAheadTaps <= RAD) {
+                    su[k % kAheadTaps] = tlo[(RAD + R - 1 + k + kAheadTaps) * RS];
+                    sd[k % kAheadTaps] = tlo[(RAD - k - kAheadTaps) * RS];
+                }
+                const f2 w2 = f2{taps.t[RAD + k], taps.t[RAD + k]};
+                // four pair sums, then their four FMAs: a packed result consumed by the very next
+                // instruction costs a wait state (the compiler paired every add with its FMA and put an
+                // s_nop between them)
+#pragma unroll
+                for (int j0 = 0; j0 < R; j0 += 4) {
+                    f2 sum[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (j0 + u < R)
+                            sum[u] = up[(j0 + u + k) % R] + dn[((j0 + u - k) % R + R) % R];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (j0 + u < R)
+                            acc[j0 + u] = pk_fma(sum[u], w2, acc[j0 + u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // (pinned: the optimiser otherwise sinks each accumulator's whole chain into its guarded
+            // store below -- one output at a time, all R + 2 RAD rows live in registers)
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                asm volatile("" : "+v"(acc[j]));
+            // branch-free buffer stores: the descriptor covers this step's rows that exist, rows past the
+            // frame fall outside it and are dropped (rw is a multiple of 4: a column pair is whole)
+            const int rows_here = min(ROWS, h - y0);
+            __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                oframe + (size_t)y0 * rw_o, 0, rows_here * rw_o * 4, 0x00027000);
+            const int voff = (R * rg * rw_o + col) * 4;
+#pragma unroll
+            for (int j = 0; j < R; j++)
+#ifdef COLSYM_NO_STORE
+                if (acc[j].x == 123.456f)
+#endif
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, acc[j]), orsrc, voff, j * rw_o * 4,
+                                                      2 /* nt */);
+        }
+        if (!more)
+            break;
+        asm volatile("" : "+v"(ts));
+        prefetch(kEarly, NPF);
+        __syncthreads();                                   // every read of this step's tile is done
+        // ---- slide: tile rows [ROWS, ROWS + 2 RAD) become rows [0, 2 RAD); every source row is in a
+        // register before anything is written (the new rows below land on source rows as well)
+        {
+            f2 mv[NMV];
+            constexpr int items = 2 * RAD * RS;
+#pragma unroll
+            for (int u = 0; u < NMV; u++) {
+                const int idx = u * 256 + ts;
+                if (idx < items)
+                    mv[u] = reinterpret_cast<const f2 *>(tile)[ROWS * RS + idx];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NMV; u++) {
+                const int idx = u * 256 + ts;
+                if (idx < items)
+                    reinterpret_cast<f2 *>(tile)[idx] = mv[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NPF; u++) {
+            const int idx = u * 256 + ts;
+            if (idx < ROWS * (kColCols / 4))
+                put4(2 * RAD + (idx >> 4), (idx & 15) * 4, pf[u]);
+        }
+        __syncthreads();
+    }
+}
+
+template <int R>
+static bool launch_col_sym(int r, const float *tmp, float *dst, int n, int h, int rw, const TapsF32 &taps,
+                           hipStream_t st)
+{
+    const int ncolt = cdiv(rw, kColCols);
+    const unsigned grid = (unsigned)((size_t)ncolt * n);
+#define VA_COL_SYM(RAD)                                                                            \
+    case RAD:                                                                                      \
+        col_sym_f32_kernel<RAD, R><<<grid, 256, (size_t)(8 * R + 2 * RAD) * kColCols * sizeof(float), st>>>( \
+            tmp, dst, h, rw, ncolt, taps);                                                         \
+        return true;
+    switch (r) {
+        VA_COL_SYM(4) VA_COL_SYM(8) VA_COL_SYM(12) VA_COL_SYM(16) VA_COL_SYM(20) VA_COL_SYM(24)
+        VA_COL_SYM(28) VA_COL_SYM(32) VA_COL_SYM(36)
+    default:
+        return false;
+    }
+#undef VA_COL_SYM
+}
+
 // chunk length for the row kernel: every CU the same work when the frame allows it
 bool plan_rows(int h, int w, int c, const TapsF32 &taps, int slots, RowPlan *plan)
 {
@@ -746,7 +984,11 @@ bool plan_rows(int h, int w, int c, const TapsF32 &taps, int slots, RowPlan *pla
     return true;
 }
 
+static int g_f32_col_generic = 0;   // test hook: the runtime-radius column kernel for every radius
+
 }  // namespace
+
+void gauss_f32_test_hook(int generic_columns) { g_f32_col_generic = generic_columns; }
 
 bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps)
 {
@@ -792,10 +1034,18 @@ int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *
     VA_LAUNCH_CHECK("ema_row_f32_kernel");
     if (prof)
         prof->mark(bg ? "ema_row_f32" : "row_f32", st);
-    const int ncolt = cdiv(rw, kColCols);
-    const size_t lds2 = (size_t)(kColRows + 2 * r) * kColStride * sizeof(float);
-    col_march_f32_kernel<<<(unsigned)((size_t)ncolt * n), 256, lds2, st>>>(scratch, dst, h, rw, ncolt, taps);
-    VA_LAUNCH_CHECK("col_march_f32_kernel");
+    // radii of integer sigmas: the unrolled 15/16-rows-per-thread kernel (whichever wastes fewer rows
+    // in the last step); any other radius: the 8-row kernel with its runtime tap loop
+    const int waste16 = cdiv(h, 128) * 128 - h, waste15 = cdiv(h, 120) * 120 - h;
+    const bool unrolled = !g_f32_col_generic &&
+                          (waste15 < waste16 ? launch_col_sym<15>(r, scratch, dst, n, h, rw, taps, st)
+                                             : launch_col_sym<16>(r, scratch, dst, n, h, rw, taps, st));
+    if (!unrolled) {
+        const int ncolt = cdiv(rw, kColCols);
+        const size_t lds2 = (size_t)(kColRows + 2 * r) * kColStride * sizeof(float);
+        col_march_f32_kernel<<<(unsigned)((size_t)ncolt * n), 256, lds2, st>>>(scratch, dst, h, rw, ncolt, taps);
+    }
+    VA_LAUNCH_CHECK("col_f32 kernel");
     if (prof)
         prof->mark("col_f32", st);
     return VA_OK;
