@@ -344,9 +344,10 @@ int va_morph_bits_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int
  * staging the mask rows in LDS even where it could read its spans straight from global memory;
  * lds_runs > 0 caps the per-frame kernel's run table (frames above it take its large-frame mode) */
 int va_test_hook_labelling(int path, int lds_runs);
-/* generic_columns != 0: every later float32 Gaussian of this process runs its column pass in the
- * runtime-radius kernel, also for the radii (r = 4, 8, ... 36) that have an unrolled one */
-int va_test_hook_gaussian_f32(int generic_columns);
+/* bit 0: every later float32 Gaussian of this process runs its column pass in the runtime-radius
+ * kernel, also for the radii (r = 4, 8, ... 36) that have an unrolled one; bit 1: the same for the
+ * row pass (compile-time-radius kernels exist for r = 8, 12, 20, 36) */
+int va_test_hook_gaussian_f32(int generic);
 
 /* ------------------------------------------------------------------ multi-GPU (RCCL)
  * Frames shard across ranks with no data-path collective; the only exchange is the final

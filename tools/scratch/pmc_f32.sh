@@ -1,0 +1,22 @@
+#!/bin/bash
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_f32
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --output-format csv -d $OUT -o $tag -- python3 $ROOT/bench.py --workload cfg5_1080p_f32x3_sigma9 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/$tag.err || { tail -5 $OUT/$tag.err; }
+done
+python3 - <<PY
+import csv, glob, collections, re
+for f in sorted(glob.glob("$OUT/*counter_collection.csv")):
+    acc = collections.defaultdict(lambda: [0, 0])
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "va::" not in k: continue
+        m = re.search(r"(\w+_kernel)", k); k = m.group(1) if m else k[:30]
+        a = acc[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+    for (k, c), (v, n) in sorted(acc.items()):
+        print("%-26s %-24s %16.0f per launch" % (k, c, v / n))
+PY

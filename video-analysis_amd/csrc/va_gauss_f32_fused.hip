@@ -41,6 +41,14 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// GLOBAL access of the wave (s_waitcnt vmcnt(0)): with loads in flight for a later phase and streaming
+// stores behind every phase that wait exposes a full memory round trip per barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if (len == 1)
@@ -506,6 +514,325 @@ ema_row_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, fl
         __syncthreads();
     }
 }
+
+// ------------------------------------------------------------------ row pass, radius at compile time
+// Second form of kernel 1 for the radii of common integer sigmas.  Same ownership (a workgroup keeps the
+// background state of its two sub-chunks in registers for all frames; loader waves / compute waves; two
+// LDS buffers) with three changes that the fixed radius allows:
+//   * the row pass is INPUT-stationary: a compute thread owns 31 consecutive outputs per half and walks
+//     over its 31 + 2rC inputs once; each input feeds the ~31/C outputs it belongs to, with the tap a
+//     compile-time index into SGPRs.  In-order per output (taps ascending), so the bits are the oracle's.
+//     8 LDS reads per output instead of 16, no register window to rotate;
+//   * therefore the staged samples can sit in LDS as PLAIN floats (the two halves of a lane's pair are
+//     two dwords 31 * 256 floats apart: one ds_read2st64_b32), a loaded float4 is staged with ONE aligned
+//     16-byte LDS write wherever it lies (no classes, no per-sample bounds: blocks are padded to float4
+//     boundaries), and results leave as aligned 16-byte LDS reads;
+//   * one workgroup of 8 waves per CU (256 VGPRs): both sub-chunks have their own load registers, so a
+//     sub-chunk's next frame is requested as soon as its current one is staged -- two phases ahead.
+namespace is {
+
+constexpr int kTW = 512;                 // loader threads: 8 waves (2 per SIMD)
+constexpr int kTC = 512;                 // compute threads: 8 waves (2 per SIMD)
+constexpr int kP2 = 15;                  // outputs per compute thread and half (odd: conflict-free LDS strides)
+constexpr int kHoff = kP2 * kTC;         // 7680 = 120 * 64 floats between the halves of a lane's pair
+constexpr int kXW = 2 * kHoff;           // window starts per buffer
+constexpr int kNS = 7;                   // float4 loads per loader thread and sub-chunk
+constexpr int kSeg = 4;                  // row pieces per sub-chunk
+
+struct Tab {
+    int cs, ce;          // flat sample range owned
+    int FS, FE;          // flat range loaded (multiples of 4)
+    int XL;              // floats of X in use
+    int rs[kSeg];        // flat index of the row start of piece k
+    int qa[kSeg], qb[kSeg];   // in-row sample range of piece k (qa == qb: unused)
+    int D[kSeg];         // in-row sample q of piece k sits at X[q + D[k]]; D % 4 == 0
+};
+
+__host__ __device__ inline int floor4(int v) { return (v >> 2) << 2; }
+__host__ __device__ inline int ceil4(int v) { return ((v + 3) >> 2) << 2; }
+
+__host__ __device__ inline Tab make_tab(int cs_in, int L, int total, int h, int rw, int halo)
+{
+    Tab T;
+    T.cs = min(cs_in, total);
+    T.ce = min(T.cs + L, total);
+    const int yfirst = T.cs / rw;
+    int end = 0;
+    T.FS = T.cs;
+    T.FE = T.ce;
+#pragma unroll
+    for (int k = 0; k < kSeg; k++) {
+        T.rs[k] = min(yfirst + k, h) * rw;
+        const int a = max(T.cs, T.rs[k]), b = min(T.ce, min(T.rs[k] + rw, total));
+        T.qa[k] = a < b ? a - T.rs[k] : 0;
+        T.qb[k] = a < b ? b - T.rs[k] : 0;
+        T.D[k] = 0;
+        if (a < b) {
+            const int lo = floor4(T.qa[k] - halo), hi = ceil4(T.qb[k] + halo);
+            T.D[k] = end + 4 - lo;                 // the block occupies X[end + 4, end + 4 + hi - lo)
+            end += 4 + (hi - lo);
+            T.FS = min(T.FS, T.rs[k] + max(0, lo));
+            T.FE = max(T.FE, T.rs[k] + min(rw, hi));
+        }
+    }
+    T.XL = end + 4;
+    return T;
+}
+
+// a sub-chunk of L flat samples fits: at most kSeg row pieces, its padded blocks inside the two halves,
+// its loads inside kNS float4 per loader thread
+inline bool fits(long long L, int rw, int halo)
+{
+    const long long ns = (L + rw - 2) / rw + 1;
+    return ns <= kSeg && L + ns * (2 * halo + 16) + 8 <= (long long)kXW &&
+           (L + 2 * halo + 8 + 3) / 4 <= (long long)kNS * kTW;
+}
+
+template <int C, int RAD>
+__global__ void __launch_bounds__(kTW + kTC)   // (HALO = RAD C <= 108 < kTW)
+row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, float *__restrict__ bg,
+                  long long n_seen, float rate, int nframes, int h, int w, int L, TapsF32 taps)
+{
+    constexpr int HALO = RAD * C, NT = 2 * RAD + 1;
+    constexpr int NIN = kP2 + 2 * HALO;              // inputs a compute thread walks over
+    constexpr int XCAP = kXW + 2 * HALO + 8;   // floats per buffer
+    __shared__ __attribute__((aligned(16))) float Xs[2][XCAP];
+    __shared__ unsigned short smap[2][kNS][kTW];
+
+    const bool ema = bg != nullptr;                  // uniform
+    const int rw = w * C, total = h * rw;
+    const size_t fstride = (size_t)total;
+    const bool loader = threadIdx.x < kTW;           // wave-uniform
+    const int tid = loader ? threadIdx.x : threadIdx.x - kTW;
+    const Tab T0 = make_tab((2 * blockIdx.x) * L, L, total, h, rw, HALO);
+    const Tab T1 = make_tab((2 * blockIdx.x + 1) * L, L, total, h, rw, HALO);
+    const int f0 = ema ? 0 : blockIdx.y, f1 = ema ? nframes : blockIdx.y + 1;
+
+    // results of a phase leave as 16-byte pieces: output float4 fo of piece k sits at
+    // O[fo - rs[k] + D[k] - HALO] (O = the buffer itself, indexed by window start).  Loader waves only:
+    // a store blocks its wave for as long as the memory system takes to accept it, and the compute waves
+    // have the next row pass to run meanwhile.
+    auto copy_out = [&](const Tab &T, const float *O, int f) {
+        char *out = reinterpret_cast<char *>(tmp + (size_t)f * fstride);
+        int fo0 = T.cs + 4 * tid;
+        asm volatile("" : "+v"(fo0));
+        const int nsl = (T.ce - T.cs + 4 * kTW - 1) / (4 * kTW);        // uniform
+        for (int m = 0; m < nsl; m++) {
+            const int fo = fo0 + 4 * kTW * m;
+            if (fo < T.ce) {
+                int p = fo - T.rs[0] + T.D[0];
+#pragma unroll
+                for (int k = 1; k < kSeg; k++)
+                    if (T.qa[k] < T.qb[k] && fo >= T.rs[k])
+                        p = fo - T.rs[k] + T.D[k];
+                const f4 v = *reinterpret_cast<const f4 *>(O + (p - HALO));
+#ifdef ROWIS_NO_STORE
+                if (v.x == 123.456f)
+#endif
+                __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (unsigned)(4 * fo)));
+            }
+        }
+    };
+
+    // ======================================================================= loader waves
+    if (loader) {
+        // where slot m of this thread (the float4 at flat index FS + 4 (tid + kT m)) is staged:
+        // X index / 4 + 1, or 0 for a slot without data
+        auto make_map = [&](const Tab &T, int sub) {
+#pragma unroll
+            for (int m = 0; m < kNS; m++) {
+                const int fm = T.FS + 4 * tid + 4 * kTW * m;
+                int info = 0;
+                if (fm < T.FE) {
+#pragma unroll
+                    for (int k = 0; k < kSeg; k++) {
+                        const int q = fm - T.rs[k];
+                        if (T.qa[k] < T.qb[k] && q >= max(0, floor4(T.qa[k] - HALO)) &&
+                            q < min(rw, ceil4(T.qb[k] + HALO)))
+                            info = ((q + T.D[k]) >> 2) + 1;
+                    }
+                }
+                smap[sub][m][tid] = (unsigned short)info;
+            }
+        };
+        make_map(T0, 0);
+        make_map(T1, 1);
+        f4 st0[kNS], st1[kNS];                       // background state of both sub-chunks (+ halos)
+        auto load_state = [&](const Tab &T, f4 (&st)[kNS]) {
+#pragma unroll
+            for (int m = 0; m < kNS; m++) {
+                const int fm = T.FS + 4 * tid + 4 * kTW * m;
+                st[m] = f4{0.f, 0.f, 0.f, 0.f};
+                if (ema && fm < T.FE)
+                    st[m] = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(bg) + (unsigned)(4 * fm));
+            }
+        };
+        load_state(T0, st0);
+        load_state(T1, st1);
+        // One register set for the loads: a sub-chunk's next frame is requested when the OTHER sub-chunk
+        // has just been staged, a whole phase (the compute waves' row pass) before it is needed.  The
+        // loads are branch-free buffer loads (slots past FE read zero, frames past the last one re-read
+        // it): behind exec-masked loads in conditional code the compiler waits vmcnt(0) before every
+        // load that reuses a register.
+        f4 ld[kNS];
+        auto issue_loads = [&](const Tab &T, int f) {
+            const int fc = min(f, f1 - 1);
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(frames) + (size_t)fc * fstride, 0, T.FE * 4, 0x00027000);
+            int fb = 4 * (T.FS + 4 * tid);
+            asm volatile("" : "+v"(fb));
+#ifdef ROWIS_NO_LOAD
+            if (rate == 123.0f)
+#endif
+#pragma unroll
+            for (int m = 0; m < kNS; m++)
+                ld[m] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, fb, 16 * kTW * m, 2 /* nt */));
+        };
+        // background update + |difference| of the loaded sub-chunk into X
+        auto stage = [&](int sub, float *X, f4 (&st)[kNS], bool first) {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+#pragma unroll
+            for (int m = 0; m < kNS; m++) {
+                const int info = smap[sub][m][t];
+                if (info != 0) {
+                    f4 v = ld[m];
+                    if (ema) {
+                        f4 s = first ? v : st[m];
+                        const f4 d = v - s;                              // oracle order: d = x - bg
+                        const f4 step = f4{rate, rate, rate, rate} * d;  // step = rate * d (no contraction)
+                        st[m] = s + step;                                // bg = bg + step
+                        v = __builtin_elementwise_abs(d);
+                    }
+                    *reinterpret_cast<f4 *>(X + 4 * (info - 1)) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // halos beyond a row end: BORDER_REFLECT_101, copied inside LDS
+        auto fixup = [&](const Tab &T, float *X) {
+#pragma unroll
+            for (int k = 0; k < kSeg; k++) {
+                if (T.qa[k] >= T.qb[k] || (T.qa[k] >= HALO && T.qb[k] + HALO <= rw))   // uniform
+                    continue;
+                int j = tid;                          // (opaque: nothing per-thread is kept across phases --
+                asm volatile("" : "+v"(j));           // it would be spilled, and a spill reload waits vmcnt(0))
+                if (j < HALO) {                       // HALO <= kTW: one sample per thread and side
+                    const int ql = T.qa[k] - HALO + j;                  // left halo sample j
+                    if (ql < 0) {                                       // w > RAD: one reflection
+                        const int px = -((-ql + C - 1) / C), ch = ql - px * C;
+                        X[ql + T.D[k]] = X[-px * C + ch + T.D[k]];
+                    }
+                    const int qr = T.qb[k] + j;                         // right halo sample j
+                    if (qr >= rw) {
+                        const int px = qr / C, ch = qr - px * C;
+                        X[qr + T.D[k]] = X[(2 * (w - 1) - px) * C + ch + T.D[k]];
+                    }
+                }
+            }
+        };
+
+        __builtin_amdgcn_s_setprio(3);
+        issue_loads(T0, f0);
+        stage(0, Xs[0], st0, ema && (n_seen + f0) == 0);
+        issue_loads(T1, f0);
+        lds_barrier();
+        fixup(T0, Xs[0]);
+        lds_barrier();
+        for (int f = f0; f < f1; f++) {
+            // ---- the compute waves filter buffer 0 (sub-chunk 0 of frame f)
+            stage(1, Xs[1], st1, ema && (n_seen + f) == 0);
+            issue_loads(T0, f + 1);
+            lds_barrier();                                              // A: row pass done, staging done
+            fixup(T1, Xs[1]);
+            lds_barrier();                                              // B: O written, buffer 1 complete
+            copy_out(T0, Xs[0], f);                                     // (the compute waves are in buffer 1)
+            // ---- buffer 1 (sub-chunk 1 of frame f)
+            if (f + 1 < f1)                                             // (the state must not see a frame twice)
+                stage(0, Xs[0], st0, false);
+            issue_loads(T1, f + 1);
+            lds_barrier();
+            fixup(T0, Xs[0]);
+            lds_barrier();
+            copy_out(T1, Xs[1], f);
+        }
+        if (ema) {
+            auto save_state = [&](const Tab &T, const f4 (&st)[kNS]) {
+#pragma unroll
+                for (int m = 0; m < kNS; m++) {
+                    const int fm = T.FS + 4 * tid + 4 * kTW * m;
+                    if (fm >= T.cs && fm < T.ce)
+                        *reinterpret_cast<f4 *>(reinterpret_cast<char *>(bg) + (unsigned)(4 * fm)) = st[m];
+                }
+            };
+            save_state(T0, st0);
+            save_state(T1, st1);
+        }
+        return;
+    }
+
+    // ====================================================================== compute waves
+    // window start p <-> output X index p + HALO; thread tid owns p = kP2 tid + j and kHoff + kP2 tid + j: the
+    // two halves of a packed operand (v_pk_fma_f32: plain v_fma_f32 has HALF the flop rate), read from LDS
+    // with one ds_read2st64_b32.  The taps are scalar operands; the set is symmetric (checked on the host),
+    // so RAD + 1 scalar registers do (2 RAD + 1 spill, and every use of a spilled one is a v_readlane).
+    auto row_pass = [&](const float *X, f2 (&acc)[kP2]) {
+        int off = kP2 * tid;
+        asm volatile("" : "+v"(off));
+        const float *xb = X + off;
+#pragma unroll
+        for (int j = 0; j < kP2; j++)
+            acc[j] = f2{0.0f, 0.0f};
+        constexpr int kAhead = 16;               // inputs in flight (x kP2 / C FMAs each): well above the LDS latency
+        f2 xs[kAhead];
+#pragma unroll
+        for (int i = 0; i < kAhead; i++)
+            xs[i] = f2{xb[i], xb[kHoff + i]};
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef ROWIS_NO_FMA
+        constexpr int kInputsRun = 12;
+#else
+        constexpr int kInputsRun = NIN;
+#endif
+#pragma clang loop unroll(full)
+        for (int i = 0; i < kInputsRun; i++) {
+            const f2 x = xs[i % kAhead];
+            if (i + kAhead < NIN)
+                xs[i % kAhead] = f2{xb[i + kAhead], xb[kHoff + i + kAhead]};
+            // input i belongs to the outputs j = i (mod C), with tap (i - j) / C
+#pragma clang loop unroll(full)
+            for (int jj = 0; jj < (kP2 + C - 1) / C; jj++) {
+                const int j = i % C + jj * C, kk = (i - j) / C;
+                if (j < kP2 && j <= i && kk < NT) {
+                    const float t = taps.t[kk <= RAD ? kk : NT - 1 - kk];
+                    acc[j] = pk_fma(x, f2{t, t}, acc[j]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto write_O = [&](float *O, const f2 (&acc)[kP2]) {
+        int off = kP2 * tid;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int j = 0; j < kP2; j++) {
+            O[off + j] = acc[j].x;
+            O[kHoff + off + j] = acc[j].y;
+        }
+    };
+    lds_barrier();          // (prologue of the loader waves)
+    lds_barrier();
+    for (int q = 0; q < 2 * (f1 - f0); q++) {        // (one copy of the unrolled row pass for both buffers)
+        float *X = Xs[q & 1];
+        f2 acc[kP2];
+        row_pass(X, acc);
+        lds_barrier();                                                  // A
+        write_O(X, acc);
+        lds_barrier();                                                  // B
+    }
+}
+
+}  // namespace is
 
 // ------------------------------------------------------------------------------ column pass
 constexpr int kColRows = 64, kColCols = 64;              // outputs per step: 8 row groups x 32 column pairs
@@ -985,10 +1312,55 @@ bool plan_rows(int h, int w, int c, const TapsF32 &taps, int slots, RowPlan *pla
 }
 
 static int g_f32_col_generic = 0;   // test hook: the runtime-radius column kernel for every radius
+static int g_f32_row_generic = 0;   // test hook: the runtime-radius row kernel for every radius
+
+// the compile-time-radius row kernel: sub-chunk length (0: shape not supported)
+static int plan_rows_is(int h, int w, int c, int r, int cus, const TapsF32 &taps)
+{
+    const int halo = r * c, rw = w * c;
+    if ((c != 1 && c != 3) || w <= r || rw % 4 != 0)
+        return 0;
+    if (r != 8 && r != 12 && r != 20 && r != 36)
+        return 0;
+    for (int k = 0; k < r; k++)                        // the kernel keeps one half of the (symmetric) tap set
+        if (taps.t[k] != taps.t[2 * r - k])
+            return 0;
+    const long long total = (long long)h * rw;
+    long long L = ((total + 2 * cus - 1) / (2 * cus) + 3) / 4 * 4;
+    if (L < 1024)
+        L = total < 1024 ? (total + 3) / 4 * 4 : 1024;
+    while (L > 4 && !is::fits(L, rw, halo))
+        L -= 4;
+    if (!is::fits(L, rw, halo) || L < 4 * c)
+        return 0;
+    return (int)L;
+}
+
+template <int C>
+static bool launch_row_is(int r, unsigned nwg, unsigned ny, const float *src, float *tmp, float *bg,
+                          long long n_seen, float rate, int n, int h, int w, int L, const TapsF32 &taps,
+                          hipStream_t st)
+{
+    const dim3 grid(nwg, ny);
+#define VA_ROW_IS(RAD)                                                                                        \
+    case RAD:                                                                                                 \
+        is::row_is_f32_kernel<C, RAD><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, n_seen, rate, n, h, w, L, taps);    \
+        return true;
+    switch (r) {
+        VA_ROW_IS(8) VA_ROW_IS(12) VA_ROW_IS(20) VA_ROW_IS(36)
+    default:
+        return false;
+    }
+#undef VA_ROW_IS
+}
 
 }  // namespace
 
-void gauss_f32_test_hook(int generic_columns) { g_f32_col_generic = generic_columns; }
+void gauss_f32_test_hook(int generic)
+{
+    g_f32_col_generic = generic & 1;
+    g_f32_row_generic = (generic >> 1) & 1;
+}
 
 bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps)
 {
@@ -1019,7 +1391,17 @@ int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *
     const size_t lds1 = 2 * (size_t)(kHalfCap + (taps.ksize - 1) * c + kP + 8) * sizeof(f2) +
                         2 * (size_t)kNV * kT * sizeof(unsigned short);
     const int nwg = (plan.nchunks + 1) / 2;          // two sub-chunks per workgroup
-    if (bg) {
+    // radii of common integer sigmas: the input-stationary kernel (one workgroup per CU)
+    const int Lis = g_f32_row_generic ? 0 : plan_rows_is(h, w, c, r, cus, taps);
+    bool rows_done = false;
+    if (Lis > 0) {
+        const long long total = (long long)h * rw;
+        const unsigned nwg2 = (unsigned)(((total + Lis - 1) / Lis + 1) / 2), ny = bg ? 1u : (unsigned)n;
+        rows_done = c == 1 ? launch_row_is<1>(r, nwg2, ny, src, scratch, bg, n_seen, (float)rate, n, h, w, Lis, taps, st)
+                           : launch_row_is<3>(r, nwg2, ny, src, scratch, bg, n_seen, (float)rate, n, h, w, Lis, taps, st);
+    }
+    if (rows_done) {
+    } else if (bg) {
         if (c == 1)
             ema_row_f32_kernel<1, true><<<nwg, 2 * kT, lds1, st>>>(src, scratch, bg, n_seen, (float)rate, n, h, w, plan.L, taps);
         else
