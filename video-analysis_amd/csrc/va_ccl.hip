@@ -1355,7 +1355,8 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
             }
         }
         carry = (lane63_m >> 31) ? lane63_label : 0;
-        __syncthreads();
+        if (w0 + kWave < w32)          // (a barrier after the last chunk would only hold the wave until its
+            __syncthreads();           // stores are acknowledged)
     }
 }
 

@@ -106,6 +106,15 @@ int launch_gauss_f32_fast(const float *src, float *dst, float *scratch, int n, i
                           const TapsF32 &taps, hipStream_t st);
 // float32 path in two kernels (va_gauss_f32_fused.hip): [EMA background + |difference| + row pass]
 // with the background state in registers, then a marching column pass.  bg == nullptr: plain blur.
+#if defined(__HIPCC__)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// GLOBAL access of the wave (s_waitcnt vmcnt(0)): with prefetch loads in flight for a later step, or
+// streaming stores behind every step, that wait exposes a memory round trip per barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#endif
 void gauss_f32_test_hook(int generic_columns);
 bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps);
 int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *bg, int64_t n_seen,

@@ -41,14 +41,6 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
-// GLOBAL access of the wave (s_waitcnt vmcnt(0)): with loads in flight for a later phase and streaming
-// stores behind every phase that wait exposes a full memory round trip per barrier.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if (len == 1)
