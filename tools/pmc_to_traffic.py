@@ -24,7 +24,8 @@ STAGE_OF_KERNEL = {
     "morph_fused_kernel": "morph_fused", "morph_stream_kernel": "morph_fused", "ccl_init_kernel": "ccl_init", "ccl_frame_kernel": "ccl_frame", "ccl_link_kernel": "ccl_link",
     "ccl_flatten_kernel": "ccl_flatten", "ccl_rowscan_kernel": "ccl_rowscan",
     "ccl_rank_kernel": "ccl_rank", "ccl_paint_kernel": "ccl_paint",
-    "ema_row_f32_kernel": "ema_row_f32", "col_march_f32_kernel": "col_f32", "unpack_bits_kernel": "mask_unpack",
+    "ema_row_f32_kernel": "ema_row_f32", "row_is_f32_kernel": "ema_row_f32",
+    "col_march_f32_kernel": "col_f32", "col_sym_f32_kernel": "col_f32", "unpack_bits_kernel": "mask_unpack",
 }
 # 8-16 B/lane coalesced streaming loads: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM)
 WIDE_STREAM_READS = {"bg", "gauss_fused", "gauss_mfma", "ema_row_f32", "col_f32"}
@@ -33,7 +34,7 @@ WIDE_STREAM_READS = {"bg", "gauss_fused", "gauss_mfma", "ema_row_f32", "col_f32"
 def per_kernel(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        m = re.search(r"va::\(anonymous namespace\)::(\w+)", r["Kernel_Name"])
+        m = re.search(r"va::\(anonymous namespace\)::(?:\w+::)*(\w+)", r["Kernel_Name"])
         if m:
             agg[m.group(1)].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
