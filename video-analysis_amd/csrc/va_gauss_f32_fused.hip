@@ -1,7 +1,9 @@
 // va_gauss_f32_fused.hip -- float32 path of BASELINE.json configs[4] in two kernels:
 //
 //   1. ema_row_f32_kernel   adaptive background (EMA) + |frame - bg| + Gaussian ROW pass
+//      (row_is_f32_kernel: the same with the radius at compile time, sigma 2 / 3 / 5 / 9)
 //   2. col_march_f32_kernel Gaussian COLUMN pass, marching down the frame
+//      (col_sym_f32_kernel: the same with the radius at compile time, r = 4, 8 ... 36)
 //
 // replaces  FilterBackground(mode='ema') (BUILD-DEFINED, arithmetic of oracle vao_bg_ema_f32)
 //           followed by cv2.GaussianBlur(float image, (0, 0), sigma),
