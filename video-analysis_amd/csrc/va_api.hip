@@ -83,6 +83,7 @@ struct va_pipeline {
     size_t frame_px;   // pixels per frame (H*W)
     int w32;
     void *bg_state;
+    void *bg_state_alt;   // fused float32 EMA: the kernel writes the new state here, then the two swap
     size_t bg_bytes;
     int64_t n_seen;
     double *bg_recip;  // per-frame reciprocals of the running mean's divisor
@@ -432,7 +433,7 @@ int va_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, do
     if (rc)
         return rc;
     if (gauss_f32_fused_supported(h, w, c, t) && reinterpret_cast<uintptr_t>(src) % 16 == 0)
-        return launch_gauss_f32_fused(src, dst, (float *)scratch.ptr, nullptr, 0, 0.0, n, h, w, c, t,
+        return launch_gauss_f32_fused(src, dst, (float *)scratch.ptr, nullptr, nullptr, 0, 0.0, n, h, w, c, t,
                                       as_stream(stream));
     if (gauss_f32_fast_supported(w, c, t))
         return launch_gauss_f32_fast(src, dst, (float *)scratch.ptr, n, h, w, c, t, as_stream(stream));
@@ -777,7 +778,7 @@ int va_contour_moments(const void *points, const int32_t *npoints, int n, int ma
 // ------------------------------------------------------------------------------ pipeline
 static int pipeline_free(va_pipeline *p)
 {
-    void *ptrs[] = {p->bg_state, p->bg_recip, p->diff, p->blur, p->gscratch, p->bits[0], p->bits[1],
+    void *ptrs[] = {p->bg_state, p->bg_state_alt, p->bg_recip, p->diff, p->blur, p->gscratch, p->bits[0], p->bits[1],
                     p->ccl_ws,   p->labels_scratch, p->counts_scratch};
     for (void *q : ptrs)
         if (q)
@@ -883,6 +884,8 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
     if (cfg->bg_mode != VA_BG_NONE) {
         p->bg_bytes = p->px * (cfg->bg_mode == VA_BG_EMA ? sizeof(float) : sizeof(double));
         PIPE_MALLOC(p->bg_state, p->bg_bytes);
+        if (p->f32_fused && cfg->bg_mode == VA_BG_EMA)
+            PIPE_MALLOC(p->bg_state_alt, p->bg_bytes);
         hipError_t e = hipMemset(p->bg_state, 0, p->bg_bytes);
         if (e != hipSuccess) {
             set_error("va_pipeline_create: hipMemset failed: %s", hipGetErrorString(e));
@@ -1018,13 +1021,17 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     // float32 frames: background update, difference and row pass in one kernel, then the columns
     if (c.dtype == VA_F32 && p->f32_fused) {
         void *dst = filtered_out ? filtered_out : p->blur;
+        const bool ema = c.bg_mode == VA_BG_EMA;
         rc = launch_gauss_f32_fused((const float *)frames, (float *)dst, (float *)p->gscratch,
-                                    c.bg_mode == VA_BG_EMA ? (float *)p->bg_state : nullptr, p->n_seen,
-                                    (double)c.bg_rate, n, c.height, c.width, c.channels, p->tf, st, prof);
+                                    ema ? (const float *)p->bg_state : nullptr,
+                                    ema ? (float *)p->bg_state_alt : nullptr, p->n_seen, (double)c.bg_rate, n,
+                                    c.height, c.width, c.channels, p->tf, st, prof);
         if (rc)
             return rc;
-        if (c.bg_mode == VA_BG_EMA)
+        if (ema && n > 0) {
+            std::swap(p->bg_state, p->bg_state_alt);      // (stream order: later runs read what this one wrote)
             p->n_seen += n;
+        }
         return VA_OK;
     }
     // 1. background subtraction (temporal, in frame order)

@@ -117,9 +117,9 @@ __device__ __forceinline__ void lds_barrier()
 #endif
 void gauss_f32_test_hook(int generic_columns);
 bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps);
-int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *bg, int64_t n_seen,
-                           double rate, int n, int h, int w, int c, const TapsF32 &taps, hipStream_t st,
-                           StageProfiler *prof = nullptr);
+int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, const float *bg, float *bg_out,
+                           int64_t n_seen, double rate, int n, int h, int w, int c, const TapsF32 &taps,
+                           hipStream_t st, StageProfiler *prof = nullptr);
 // fused single-channel u8 Gaussian (LDS-staged, dot4/dot2), radius <= 31; output either the
 // blurred u8 frames (dst), and/or the thresholded bit mask (bits, blurred > thresh)
 bool gauss_fused_supported(int w, int h, const TapsQ8 &taps);

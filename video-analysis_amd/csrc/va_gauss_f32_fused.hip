@@ -124,8 +124,9 @@ __device__ __forceinline__ ChunkTab make_tab(int cs_in, int L, int total, int h,
 // 2.9 ms + 2.4 ms).  Two workgroups per CU: 2 compute + 2 loader waves per SIMD.
 template <int C, bool EMA>
 __global__ void __launch_bounds__(2 * kT, 4)
-ema_row_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, float *__restrict__ bg,
-                   long long n_seen, float rate, int nframes, int h, int w, int L, TapsF32 taps)
+ema_row_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, const float *__restrict__ bg,
+                   float *__restrict__ bg_out, long long n_seen, float rate, int nframes, int h, int w, int L,
+                   TapsF32 taps)
 {
     extern __shared__ f2 lds[];    // [buffer 0][buffer 1][staging map]
     constexpr int WIN = kP + C;
@@ -378,7 +379,7 @@ ema_row_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, fl
                 for (int m = 0; m < kNV; m++) {
                     const int fm = T.FS + 4 * tid + 4 * kT * m;
                     if (fm >= T.cs && fm < T.ce)                      // only the sub-chunk's own samples
-                        *reinterpret_cast<f4 *>(reinterpret_cast<char *>(bg) + (unsigned)(4 * fm)) =
+                        *reinterpret_cast<f4 *>(reinterpret_cast<char *>(bg_out) + (unsigned)(4 * fm)) =
                             f4{st[m][0], st[m][1], st[m][2], st[m][3]};
                 }
             };
@@ -584,8 +585,9 @@ inline bool fits(long long L, int rw, int halo)
 
 template <int C, int RAD>
 __global__ void __launch_bounds__(kTW + kTC)   // (HALO = RAD C <= 108 < kTW)
-row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, float *__restrict__ bg,
-                  long long n_seen, float rate, int nframes, int h, int w, int L, TapsF32 taps)
+row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, const float *__restrict__ bg,
+                  float *__restrict__ bg_out, long long n_seen, float rate, int nframes, int h, int w, int L,
+                  TapsF32 taps)
 {
     constexpr int HALO = RAD * C, NT = 2 * RAD + 1;
     constexpr int NIN = kP2 + 2 * HALO;              // inputs a compute thread walks over
@@ -733,6 +735,7 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, flo
         lds_barrier();
         fixup(T0, Xs[0]);
         lds_barrier();
+        lds_barrier();                                                  // (the C of the compute waves' first row pass)
         for (int f = f0; f < f1; f++) {
             // ---- the compute waves filter buffer 0 (sub-chunk 0 of frame f)
             stage(1, Xs[1], st1, ema && (n_seen + f) == 0);
@@ -742,21 +745,25 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, flo
             lds_barrier();                                              // B: O written, buffer 1 complete
             copy_out(T0, Xs[0], f);                                     // (the compute waves are in buffer 1)
             // ---- buffer 1 (sub-chunk 1 of frame f)
-            if (f + 1 < f1)                                             // (the state must not see a frame twice)
-                stage(0, Xs[0], st0, false);
+            lds_barrier();                                              // C: every loader wave has copied buffer 0 out
+            if (f + 1 < f1)                                             //    (the compute waves pass C half-way through
+                stage(0, Xs[0], st0, false);                            //    their row pass; the state must not see a frame twice)
             issue_loads(T1, f + 1);
             lds_barrier();
             fixup(T0, Xs[0]);
             lds_barrier();
             copy_out(T1, Xs[1], f);
+            lds_barrier();                                              // C: buffer 1 copied out before it is staged again
         }
         if (ema) {
+            // into a SECOND buffer: a neighbouring workgroup that starts late reads the halo of its chunk
+            // -- samples this workgroup owns -- from `bg`, which must still hold the state before the batch
             auto save_state = [&](const Tab &T, const f4 (&st)[kNS]) {
 #pragma unroll
                 for (int m = 0; m < kNS; m++) {
                     const int fm = T.FS + 4 * tid + 4 * kTW * m;
                     if (fm >= T.cs && fm < T.ce)
-                        *reinterpret_cast<f4 *>(reinterpret_cast<char *>(bg) + (unsigned)(4 * fm)) = st[m];
+                        *reinterpret_cast<f4 *>(reinterpret_cast<char *>(bg_out) + (unsigned)(4 * fm)) = st[m];
                 }
             };
             save_state(T0, st0);
@@ -790,6 +797,10 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, flo
 #endif
 #pragma clang loop unroll(full)
         for (int i = 0; i < kInputsRun; i++) {
+            // barrier C of the loader waves (the buffer they copied out may be staged again): passed here,
+            // half-way, so that neither side waits for long
+            if (i == kInputsRun / 2)
+                lds_barrier();
             const f2 x = xs[i % kAhead];
             if (i + kAhead < NIN)
                 xs[i % kAhead] = f2{xb[i + kAhead], xb[kHoff + i + kAhead]};
@@ -816,14 +827,16 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, flo
     };
     lds_barrier();          // (prologue of the loader waves)
     lds_barrier();
-    for (int q = 0; q < 2 * (f1 - f0); q++) {        // (one copy of the unrolled row pass for both buffers)
+    const int Q = 2 * (f1 - f0);
+    for (int q = 0; q < Q; q++) {                    // (one copy of the unrolled row pass for both buffers)
         float *X = Xs[q & 1];
         f2 acc[kP2];
-        row_pass(X, acc);
+        row_pass(X, acc);                            // (barrier C of the previous phase's copy-out inside)
         lds_barrier();                                                  // A
         write_O(X, acc);
         lds_barrier();                                                  // B
     }
+    lds_barrier();                                                      // (the C after the last copy-out)
 }
 
 }  // namespace is
@@ -1331,14 +1344,14 @@ static int plan_rows_is(int h, int w, int c, int r, int cus, const TapsF32 &taps
 }
 
 template <int C>
-static bool launch_row_is(int r, unsigned nwg, unsigned ny, const float *src, float *tmp, float *bg,
-                          long long n_seen, float rate, int n, int h, int w, int L, const TapsF32 &taps,
-                          hipStream_t st)
+static bool launch_row_is(int r, unsigned nwg, unsigned ny, const float *src, float *tmp, const float *bg,
+                          float *bg_out, long long n_seen, float rate, int n, int h, int w, int L,
+                          const TapsF32 &taps, hipStream_t st)
 {
     const dim3 grid(nwg, ny);
 #define VA_ROW_IS(RAD)                                                                                        \
     case RAD:                                                                                                 \
-        is::row_is_f32_kernel<C, RAD><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, n_seen, rate, n, h, w, L, taps);    \
+        is::row_is_f32_kernel<C, RAD><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, bg_out, n_seen, rate, n, h, w, L, taps); \
         return true;
     switch (r) {
         VA_ROW_IS(8) VA_ROW_IS(12) VA_ROW_IS(20) VA_ROW_IS(36)
@@ -1365,11 +1378,13 @@ bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps)
     return plan_rows(h, w, c, taps, 1024, &p);
 }
 
-// bg == nullptr: plain blur of the frames; otherwise EMA background subtraction first
-int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *bg, int64_t n_seen,
-                           double rate, int n, int h, int w, int c, const TapsF32 &taps, hipStream_t st,
-                           StageProfiler *prof)
+// bg == nullptr: plain blur of the frames; otherwise EMA background subtraction first: the state before the
+// batch is read from bg, the state after it is written to bg_out (a different buffer: see save_state)
+int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, const float *bg, float *bg_out,
+                           int64_t n_seen, double rate, int n, int h, int w, int c, const TapsF32 &taps,
+                           hipStream_t st, StageProfiler *prof)
 {
+    VA_REQUIRE(!bg || (bg_out && bg_out != bg), "fused float gaussian: the state needs a second buffer");
     RowPlan plan;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -1377,7 +1392,7 @@ int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *
         cus = 256;
     VA_REQUIRE(plan_rows(h, w, c, taps, 4 * cus, &plan), "fused float gaussian: unsupported shape");
     VA_REQUIRE(reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(scratch) % 16 == 0 &&
-                   (!bg || reinterpret_cast<uintptr_t>(bg) % 16 == 0),
+                   (!bg || (reinterpret_cast<uintptr_t>(bg) % 16 == 0 && reinterpret_cast<uintptr_t>(bg_out) % 16 == 0)),
                "fused float gaussian: buffers must be 16-byte aligned");
     if (n == 0 || h == 0)
         return VA_OK;
@@ -1391,21 +1406,21 @@ int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, float *
     if (Lis > 0) {
         const long long total = (long long)h * rw;
         const unsigned nwg2 = (unsigned)(((total + Lis - 1) / Lis + 1) / 2), ny = bg ? 1u : (unsigned)n;
-        rows_done = c == 1 ? launch_row_is<1>(r, nwg2, ny, src, scratch, bg, n_seen, (float)rate, n, h, w, Lis, taps, st)
-                           : launch_row_is<3>(r, nwg2, ny, src, scratch, bg, n_seen, (float)rate, n, h, w, Lis, taps, st);
+        rows_done = c == 1 ? launch_row_is<1>(r, nwg2, ny, src, scratch, bg, bg_out, n_seen, (float)rate, n, h, w, Lis, taps, st)
+                           : launch_row_is<3>(r, nwg2, ny, src, scratch, bg, bg_out, n_seen, (float)rate, n, h, w, Lis, taps, st);
     }
     if (rows_done) {
     } else if (bg) {
         if (c == 1)
-            ema_row_f32_kernel<1, true><<<nwg, 2 * kT, lds1, st>>>(src, scratch, bg, n_seen, (float)rate, n, h, w, plan.L, taps);
+            ema_row_f32_kernel<1, true><<<nwg, 2 * kT, lds1, st>>>(src, scratch, bg, bg_out, n_seen, (float)rate, n, h, w, plan.L, taps);
         else
-            ema_row_f32_kernel<3, true><<<nwg, 2 * kT, lds1, st>>>(src, scratch, bg, n_seen, (float)rate, n, h, w, plan.L, taps);
+            ema_row_f32_kernel<3, true><<<nwg, 2 * kT, lds1, st>>>(src, scratch, bg, bg_out, n_seen, (float)rate, n, h, w, plan.L, taps);
     } else {
         const dim3 grid((unsigned)nwg, (unsigned)n);
         if (c == 1)
-            ema_row_f32_kernel<1, false><<<grid, 2 * kT, lds1, st>>>(src, scratch, nullptr, 0, 0.f, n, h, w, plan.L, taps);
+            ema_row_f32_kernel<1, false><<<grid, 2 * kT, lds1, st>>>(src, scratch, nullptr, nullptr, 0, 0.f, n, h, w, plan.L, taps);
         else
-            ema_row_f32_kernel<3, false><<<grid, 2 * kT, lds1, st>>>(src, scratch, nullptr, 0, 0.f, n, h, w, plan.L, taps);
+            ema_row_f32_kernel<3, false><<<grid, 2 * kT, lds1, st>>>(src, scratch, nullptr, nullptr, 0, 0.f, n, h, w, plan.L, taps);
     }
     VA_LAUNCH_CHECK("ema_row_f32_kernel");
     if (prof)
