@@ -250,6 +250,29 @@ def test_gaussian_f32_column_kernels(oracle):
             assert np.array_equal(gen.view(np.uint32), ref.view(np.uint32)), (shape, sigma, "generic")
 
 
+def test_f32_ema_short_runs_and_restaging(oracle):
+    """regression for two races of the fused float32 EMA path (found by tools/stress_f32_kernels.py): frames fed
+    one per run (a late workgroup must not see its neighbour's already advanced halo state), and several frames
+    per run on small frames (a loader wave must not restage an LDS buffer another one still copies out)"""
+    rng = np.random.default_rng(99)
+    for rep in range(4):
+        for (n, h, w, c, sigma, rate, per_run) in ((6, 138, 1920, 3, 2.0, 1.0, 1), (3, 240, 1920, 3, 2.0, 0.3, 3),
+                                                  (4, 379, 1280, 1, 1.0, 0.3, 1), (6, 125, 1280, 3, 4.0, 1.0, 2)):
+            shape = (n, h, w, c) if c == 3 else (n, h, w)
+            clip = (rng.random(shape, dtype=np.float32) * 2 - 0.5).astype(np.float32)
+            eng = _engine(size=(w, h), channels=c, dtype=np.float32, max_batch=n, background="ema", bg_rate=rate,
+                          sigma=sigma)
+            got = np.concatenate([eng.run(clip[i:i + per_run], want=("filtered",))["filtered"]
+                                  for i in range(0, n, per_run)])
+            state, seen = eng.get_background()
+            eng.close()
+            diff, bg = oracle.bg_ema_f32(clip.reshape(n, -1), rate=np.float32(rate))
+            ref = oracle.gaussian_f32(diff.reshape(shape), sigma)
+            assert seen == n
+            assert np.array_equal(state.ravel().view(np.uint32), bg.ravel().view(np.uint32)), (shape, "state")
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (shape, sigma, rate, per_run)
+
+
 def test_stress_slice_round2_paths(oracle):
     """a bounded, seeded slice of tools/stress_misc.py: float32 EMA + blur through the pipeline at random
     shapes with split batches, cv2.resize in every mode, contour moments of traced contours"""
