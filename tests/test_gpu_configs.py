@@ -273,6 +273,25 @@ def test_f32_ema_short_runs_and_restaging(oracle):
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (shape, sigma, rate, per_run)
 
 
+def test_f32_ema_4k_more_chunks_than_cus(oracle):
+    """3840x2160x3 float32: the row kernel's chunks outnumber the CUs, so workgroups of a later round start
+    after earlier ones have finished -- they must still read the state from BEFORE the batch for their halos"""
+    n, h, w, c, sigma, rate = 3, 2160, 3840, 3, 2.0, 0.3
+    rng = np.random.default_rng(4)
+    clip = (rng.random((n, h, w, c), dtype=np.float32) * 2 - 0.5).astype(np.float32)
+    eng = _engine(size=(w, h), channels=c, dtype=np.float32, max_batch=n, background="ema", bg_rate=rate,
+                  sigma=sigma)
+    got = np.concatenate([eng.run(clip[:2], want=("filtered",))["filtered"],
+                          eng.run(clip[2:], want=("filtered",))["filtered"]])
+    state, seen = eng.get_background()
+    eng.close()
+    diff, bg = oracle.bg_ema_f32(clip.reshape(n, -1), rate=np.float32(rate))
+    ref = oracle.gaussian_f32(diff.reshape(clip.shape), sigma)
+    assert seen == n
+    assert np.array_equal(state.ravel().view(np.uint32), bg.ravel().view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_stress_slice_round2_paths(oracle):
     """a bounded, seeded slice of tools/stress_misc.py: float32 EMA + blur through the pipeline at random
     shapes with split batches, cv2.resize in every mode, contour moments of traced contours"""
