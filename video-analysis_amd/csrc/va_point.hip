@@ -100,11 +100,17 @@ bg_reciprocals_kernel(double *__restrict__ y, long long n_seen, int n)
         y[f] = 1.0 / (double)(n_seen + f + 1);
 }
 
-template <int V>
+// the reciprocals of a batch of up to 256 frames travel in the kernel arguments (divided on the host:
+// IEEE division either way), which saves the launch of bg_reciprocals_kernel and its place in the queue
+struct RecipArgs {
+    double r[256];
+    __device__ double operator[](int f) const { return r[f]; }
+};
+
+template <int V, typename RECIP>
 __global__ void __launch_bounds__(kBlock)
 bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff,
-                       double *__restrict__ mean, const double *__restrict__ recip,
-                       long long n_seen, int n, size_t px)
+                       double *__restrict__ mean, const RECIP recip, long long n_seen, int n, size_t px)
 {
     size_t i0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * V;
     if (i0 >= px)
@@ -424,16 +430,27 @@ int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, 
         bool vec = (px % kVec == 0) && aligned(fr, 8) && (!df || aligned(df, 8));
         int grid = vec ? cdiv((long long)(px / kVec), kBlock) : cdiv((long long)px, kBlock);
         if (mode == VA_BG_MEAN) {
-            if (vec && recip_scratch) {
+            // 16 px per thread when the streams allow 16-byte pieces (1 KB per wave instruction)
+            const bool wide = px % 16 == 0 && aligned(fr, 16) && (!df || aligned(df, 16));
+            if (vec && n <= 256) {
+                RecipArgs ra;
+                for (int f = 0; f < 256; f++)
+                    ra.r[f] = 1.0 / (double)(n_seen + (f < n ? f : 0) + 1);
+                if (wide)
+                    bg_mean_u8_fast_kernel<16, RecipArgs><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
+                        fr, df, (double *)state, ra, n_seen, n, px);
+                else
+                    bg_mean_u8_fast_kernel<8, RecipArgs><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, ra,
+                                                                                 n_seen, n, px);
+            } else if (vec && recip_scratch) {
                 bg_reciprocals_kernel<<<cdiv(n, kBlock), kBlock, 0, st>>>(recip_scratch, n_seen, n);
                 VA_LAUNCH_CHECK("bg_reciprocals_kernel");
-                // 16 px per thread when the streams allow 16-byte pieces (1 KB per wave instruction)
-                if (px % 16 == 0 && aligned(fr, 16) && (!df || aligned(df, 16)))
-                    bg_mean_u8_fast_kernel<16><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
+                if (wide)
+                    bg_mean_u8_fast_kernel<16, const double *><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
                         fr, df, (double *)state, recip_scratch, n_seen, n, px);
                 else
-                    bg_mean_u8_fast_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (double *)state,
-                                                                      recip_scratch, n_seen, n, px);
+                    bg_mean_u8_fast_kernel<8, const double *><<<grid, kBlock, 0, st>>>(
+                        fr, df, (double *)state, recip_scratch, n_seen, n, px);
             } else if (vec)
                 bg_mean_u8_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, n_seen, n, px);
             else
