@@ -250,6 +250,25 @@ def test_gaussian_f32_column_kernels(oracle):
             assert np.array_equal(gen.view(np.uint32), ref.view(np.uint32)), (shape, sigma, "generic")
 
 
+def test_running_mean_user_state_in_and_out_of_u8_range(oracle):
+    """the pipeline's running mean drops the saturation of |frame - mean| while its state is known to lie in
+    [0, 255]; a state set from outside that range (va_bg_set_state) must bring the saturating kernel back"""
+    rng = np.random.default_rng(8)
+    n, h, w = 7, 48, 160                                   # 16-byte rows: the wide kernel
+    clip = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    for lo, hi in ((0.0, 255.0), (-50.0, 700.0)):
+        state0 = rng.uniform(lo, hi, (h, w))
+        eng = _engine(size=(w, h), max_batch=n, background="mean")
+        eng.set_background(state0, 5)
+        got = eng.run(clip, want=("filtered",))["filtered"]
+        state, seen = eng.get_background()
+        eng.close()
+        ref, mean = oracle.bg_mean_u8(clip, state0, 5)
+        assert seen == 5 + n
+        assert np.array_equal(got, ref), (lo, hi)
+        assert np.array_equal(state.view(np.uint64), mean.view(np.uint64)), (lo, hi)
+
+
 def test_f32_ema_short_runs_and_restaging(oracle):
     """regression for two races of the fused float32 EMA path (found by tools/stress_f32_kernels.py): frames fed
     one per run (a late workgroup must not see its neighbour's already advanced halo state), and several frames

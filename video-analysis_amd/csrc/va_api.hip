@@ -84,6 +84,7 @@ struct va_pipeline {
     int w32;
     void *bg_state;
     void *bg_state_alt;   // fused float32 EMA: the kernel writes the new state here, then the two swap
+    bool bg_in_u8_range;  // running mean: every state value is known to lie in [0, 255]
     size_t bg_bytes;
     int64_t n_seen;
     double *bg_recip;  // per-frame reciprocals of the running mean's divisor
@@ -886,6 +887,7 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
         PIPE_MALLOC(p->bg_state, p->bg_bytes);
         if (p->f32_fused && cfg->bg_mode == VA_BG_EMA)
             PIPE_MALLOC(p->bg_state_alt, p->bg_bytes);
+        p->bg_in_u8_range = true;                        // (zeros)
         hipError_t e = hipMemset(p->bg_state, 0, p->bg_bytes);
         if (e != hipSuccess) {
             set_error("va_pipeline_create: hipMemset failed: %s", hipGetErrorString(e));
@@ -981,9 +983,18 @@ int va_bg_set_state(va_pipeline_t *p, const void *state_host, size_t bytes, int6
             VA_HIP(hipDeviceSynchronize());
             VA_HIP(hipMemcpy(p->bg_state, state_host, bytes, hipMemcpyHostToDevice));
         }
+        p->bg_in_u8_range = false;
+        if (p->cfg.bg_mode == VA_BG_MEAN) {              // (float64 state)
+            const double *m = static_cast<const double *>(state_host);
+            bool ok = true;
+            for (size_t i = 0; i < bytes / sizeof(double) && ok; i++)
+                ok = m[i] >= 0.0 && m[i] <= 255.0;       // (false for NaN)
+            p->bg_in_u8_range = ok;
+        }
     } else if (p->bg_bytes) {
         VA_HIP(hipDeviceSynchronize());
         VA_HIP(hipMemset(p->bg_state, 0, p->bg_bytes));
+        p->bg_in_u8_range = true;
     }
     p->n_seen = n_seen;
     return VA_OK;
@@ -1037,7 +1048,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     // 1. background subtraction (temporal, in frame order)
     if (c.bg_mode != VA_BG_NONE) {
         rc = launch_bg(c.bg_mode, c.dtype, cur, p->diff, p->bg_state, p->n_seen, (double)c.bg_rate,
-                       n, p->px, st, p->bg_recip);
+                       n, p->px, st, p->bg_recip, p->bg_in_u8_range);
         if (rc)
             return rc;
         p->n_seen += n;

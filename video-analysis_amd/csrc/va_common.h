@@ -132,10 +132,12 @@ int launch_gauss_mfma_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int t
                          int h, int w, const TapsQ8 &taps, hipStream_t st);
 
 // recip_scratch: bg_scratch_bytes(n) bytes of device memory for the per-frame reciprocals of the
-// division-free running mean (nullptr: the plain-division kernel is used)
+// division-free running mean of batches above 256 frames (nullptr: the plain-division kernel is used);
+// mean_in_u8_range: the caller vouches that the running-mean state lies in [0, 255] (saturation-free kernel)
 size_t bg_scratch_bytes(int n);
 int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, int64_t n_seen,
-              double rate, int n, size_t px, hipStream_t st, double *recip_scratch = nullptr);
+              double rate, int n, size_t px, hipStream_t st, double *recip_scratch = nullptr,
+              bool mean_in_u8_range = false);
 int launch_welford(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
                    size_t px, hipStream_t st);
 

@@ -107,7 +107,10 @@ struct RecipArgs {
     __device__ double operator[](int f) const { return r[f]; }
 };
 
-template <int V, typename RECIP>
+// BOUNDED: the caller vouches that every mean lies in [0, 255] (true for a state that started at zero or
+// inside that range: a mean of uint8 values stays there up to rounding), so |frame - mean| < 256 and the
+// saturation of the difference -- one of the 14 operations per pixel -- can go
+template <int V, typename RECIP, bool BOUNDED>
 __global__ void __launch_bounds__(kBlock)
 bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff,
                        double *__restrict__ mean, const RECIP recip, long long n_seen, int n, size_t px)
@@ -153,7 +156,7 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
 #pragma unroll
             for (int k = 0; k < V; k++) {
                 const double fr = (double)p[k];
-                o[k] = sat_u8_trunc(fabs(fr - m[k]));
+                o[k] = BOUNDED ? (uint8_t)(int)fabs(fr - m[k]) : sat_u8_trunc(fabs(fr - m[k]));
                 m[k] = div_by_uniform(m[k] * dn, dn1, y) + div_by_uniform(fr, dn1, y);
             }
             if (diff) {
@@ -418,7 +421,7 @@ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_
 size_t bg_scratch_bytes(int n) { return sizeof(double) * (size_t)(n > 0 ? n : 1); }
 
 int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, int64_t n_seen,
-              double rate, int n, size_t px, hipStream_t st, double *recip_scratch)
+              double rate, int n, size_t px, hipStream_t st, double *recip_scratch, bool mean_in_u8_range)
 {
     VA_REQUIRE(frames && state, "va_bg_update: frames/state must not be NULL");
     VA_REQUIRE(n >= 0 && px > 0, "va_bg_update: bad sizes n=%d px=%zu", n, px);
@@ -436,20 +439,23 @@ int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, 
                 RecipArgs ra;
                 for (int f = 0; f < 256; f++)
                     ra.r[f] = 1.0 / (double)(n_seen + (f < n ? f : 0) + 1);
-                if (wide)
-                    bg_mean_u8_fast_kernel<16, RecipArgs><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
+                if (wide && mean_in_u8_range)
+                    bg_mean_u8_fast_kernel<16, RecipArgs, true><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
+                        fr, df, (double *)state, ra, n_seen, n, px);
+                else if (wide)
+                    bg_mean_u8_fast_kernel<16, RecipArgs, false><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
                         fr, df, (double *)state, ra, n_seen, n, px);
                 else
-                    bg_mean_u8_fast_kernel<8, RecipArgs><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, ra,
-                                                                                 n_seen, n, px);
+                    bg_mean_u8_fast_kernel<8, RecipArgs, false><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, ra,
+                                                                                        n_seen, n, px);
             } else if (vec && recip_scratch) {
                 bg_reciprocals_kernel<<<cdiv(n, kBlock), kBlock, 0, st>>>(recip_scratch, n_seen, n);
                 VA_LAUNCH_CHECK("bg_reciprocals_kernel");
                 if (wide)
-                    bg_mean_u8_fast_kernel<16, const double *><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
+                    bg_mean_u8_fast_kernel<16, const double *, false><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
                         fr, df, (double *)state, recip_scratch, n_seen, n, px);
                 else
-                    bg_mean_u8_fast_kernel<8, const double *><<<grid, kBlock, 0, st>>>(
+                    bg_mean_u8_fast_kernel<8, const double *, false><<<grid, kBlock, 0, st>>>(
                         fr, df, (double *)state, recip_scratch, n_seen, n, px);
             } else if (vec)
                 bg_mean_u8_kernel<8><<<grid, kBlock, 0, st>>>(fr, df, (double *)state, n_seen, n, px);
