@@ -25,7 +25,7 @@ STAGE_OF_KERNEL = {
     "ccl_flatten_kernel": "ccl_flatten", "ccl_rowscan_kernel": "ccl_rowscan",
     "ccl_rank_kernel": "ccl_rank", "ccl_paint_kernel": "ccl_paint",
     "ema_row_f32_kernel": "ema_row_f32", "row_is_f32_kernel": "ema_row_f32",
-    "col_march_f32_kernel": "col_f32", "col_sym_f32_kernel": "col_f32", "unpack_bits_kernel": "mask_unpack",
+    "col_march_f32_kernel": "col_f32", "col_sym_f32_kernel": "col_f32", "unpack_bits_kernel": "mask_unpack", "unpack_bits_wide_kernel": "mask_unpack",
 }
 # 8-16 B/lane coalesced streaming loads: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM)
 WIDE_STREAM_READS = {"bg", "gauss_fused", "gauss_mfma", "ema_row_f32", "col_f32"}
