@@ -435,11 +435,8 @@ int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, 
         int grid = vec ? cdiv((long long)(px / kVec), kBlock) : cdiv((long long)px, kBlock);
         if (mode == VA_BG_MEAN) {
             // 16 px per thread when the streams allow 16-byte pieces (1 KB per wave instruction)
-#ifdef VA_BG_NARROW
-            const bool wide = false;
-#else
+            // (8 px per thread, i.e. twice the waves with 8-byte accesses: 0.271-0.276 against 0.259-0.265 ms)
             const bool wide = px % 16 == 0 && aligned(fr, 16) && (!df || aligned(df, 16));
-#endif
             if (vec && n <= 256) {
                 RecipArgs ra;
                 for (int f = 0; f < 256; f++)
