@@ -346,7 +346,7 @@ int va_morph_bits_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int
 int va_test_hook_labelling(int path, int lds_runs);
 /* bit 0: every later float32 Gaussian of this process runs its column pass in the runtime-radius
  * kernel, also for the radii (r = 4, 8, ... 36) that have an unrolled one; bit 1: the same for the
- * row pass (compile-time-radius kernels exist for r = 8, 12, 20, 36) */
+ * row pass (compile-time-radius kernels exist for the same radii) */
 int va_test_hook_gaussian_f32(int generic);
 
 /* ------------------------------------------------------------------ multi-GPU (RCCL)

@@ -1,7 +1,7 @@
 // va_gauss_f32_fused.hip -- float32 path of BASELINE.json configs[4] in two kernels:
 //
 //   1. ema_row_f32_kernel   adaptive background (EMA) + |frame - bg| + Gaussian ROW pass
-//      (row_is_f32_kernel: the same with the radius at compile time, sigma 2 / 3 / 5 / 9)
+//      (row_is_f32_kernel: the same with the radius at compile time, r = 4, 8 ... 36)
 //   2. col_march_f32_kernel Gaussian COLUMN pass, marching down the frame
 //      (col_sym_f32_kernel: the same with the radius at compile time, r = 4, 8 ... 36)
 //
@@ -511,7 +511,7 @@ ema_row_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, co
 }
 
 // ------------------------------------------------------------------ row pass, radius at compile time
-// Second form of kernel 1 for the radii of common integer sigmas.  Same ownership (a workgroup keeps the
+// Second form of kernel 1 for the radii of integer sigmas (r = 4 sigma = 4 ... 36).  Same ownership (a workgroup keeps the
 // background state of its two sub-chunks in registers for all frames; loader waves / compute waves; two
 // LDS buffers) with three changes that the fixed radius allows:
 //   * the row pass is INPUT-stationary: a compute thread owns 31 consecutive outputs per half and walks
@@ -1327,7 +1327,7 @@ static int plan_rows_is(int h, int w, int c, int r, int cus, const TapsF32 &taps
     const int halo = r * c, rw = w * c;
     if ((c != 1 && c != 3) || w <= r || rw % 4 != 0)
         return 0;
-    if (r != 8 && r != 12 && r != 20 && r != 36)
+    if (r < 4 || r > 36 || r % 4 != 0)                 // integer sigmas 1 ... 9 (r = 4 sigma)
         return 0;
     for (int k = 0; k < r; k++)                        // the kernel keeps one half of the (symmetric) tap set
         if (taps.t[k] != taps.t[2 * r - k])
@@ -1354,7 +1354,8 @@ static bool launch_row_is(int r, unsigned nwg, unsigned ny, const float *src, fl
         is::row_is_f32_kernel<C, RAD><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, bg_out, n_seen, rate, n, h, w, L, taps); \
         return true;
     switch (r) {
-        VA_ROW_IS(8) VA_ROW_IS(12) VA_ROW_IS(20) VA_ROW_IS(36)
+        VA_ROW_IS(4) VA_ROW_IS(8) VA_ROW_IS(12) VA_ROW_IS(16) VA_ROW_IS(20) VA_ROW_IS(24) VA_ROW_IS(28) VA_ROW_IS(32)
+        VA_ROW_IS(36)
     default:
         return false;
     }
