@@ -16,8 +16,14 @@ eng = FrameEngine(size=(w, h), max_batch=n, background="mean", sigma=5.0, thresh
 st = torch.cuda.current_stream(dev).cuda_stream
 L = _hip.lib()
 buf = (C.c_longlong * 16)()
-for rep in range(4):
+xb = (C.c_int * 32)()
+for rep in range(12):
+    eng.profile(True)
     eng.run_device(frames.data_ptr(), n, None, None, labels.data_ptr(), counts.data_ptr(), None, st)
     torch.cuda.synchronize()
+    stt = eng.stage_times(); eng.profile(False)
+    L.va_debug_ccl_xcc.argtypes = [C.c_void_p]; L.va_debug_ccl_xcc(xb)
+    print("frame WGs 0..7 on XCC", list(xb[0:8]), " paint blocks 0..7 on XCC", list(xb[16:24]),
+          " paint %.4f ms" % (stt["ccl_paint"][0] / stt["ccl_paint"][1]))
     L.va_debug_ccl_stamps.argtypes = [C.c_void_p]
     print(L.va_debug_ccl_stamps(buf), [ (buf[i+1]-buf[i])/100.0 for i in range(6)], "| link:", [buf[i]/100.0 for i in range(8,12)], int(counts.sum()))

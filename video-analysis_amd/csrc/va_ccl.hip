@@ -715,6 +715,7 @@ __device__ __forceinline__ void scan_rows(int *rowbase, int h, int *s_part, int 
 // so does the contour tracer, which reads roots at first pixels (table == nullptr).
 #ifdef VA_CCL_STAMPS
 __device__ long long g_ccl_stamps[16];
+__device__ int g_ccl_xcc[2][16];      // XCC_ID of the first 16 workgroups of ccl_frame [0] and ccl_paint [1]
 #define CCL_ACC(v, t0) do { long long t1_ = __builtin_amdgcn_s_memtime(); v += t1_ - t0; t0 = t1_; } while (0)
 #define CCL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ccl_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -733,6 +734,10 @@ ccl_frame_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     __shared__ int s_total;
 
     const int f = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & (kWave - 1);
+#ifdef VA_CCL_STAMPS
+    if (tid == 0 && f < 16)
+        g_ccl_xcc[0][f] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;     // HW_REG_XCC_ID
+#endif
     const uint32_t *fbits = bits + (size_t)f * h * w32;
     int32_t *L = labels + (size_t)f * h * w;
     int *stage = s_mem + wv * lay.stage_words + kStagePad;   // slot j <-> image row y0 - 1 + j
@@ -1199,6 +1204,10 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     __shared__ int32_t s_lab[kRowsPerBlock][kWave][16];
 
     RowCtx c = row_ctx(h, total_rows);
+#ifdef VA_CCL_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 16)
+        g_ccl_xcc[1][blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
+#endif
     if (xcd_frames) {
         // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs and the per-frame
         // labelling kernel ran frame f on XCD f % 8 (one workgroup per frame), so the run table, the
@@ -1854,5 +1863,9 @@ int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, i
 extern "C" int va_debug_ccl_stamps(long long *host)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(va::g_ccl_stamps), sizeof(long long) * 16);
+}
+extern "C" int va_debug_ccl_xcc(int *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(va::g_ccl_xcc), sizeof(int) * 32);
 }
 #endif
