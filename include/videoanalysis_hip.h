@@ -307,6 +307,22 @@ int va_pipeline_destroy(va_pipeline_t *p);
 int va_pipeline_run(va_pipeline_t *p, const void *frames_dev, int n, void *filtered_out_dev,
                     uint8_t *mask_out_dev, int32_t *labels_out_dev, int32_t *counts_out_dev,
                     int64_t *stats_out_dev, void *stream);
+/* Overlapped runs (off by default).  The chain's last kernel -- the write of the int32 label image and
+ * the per-label statistics, which get_largest_region / regionprops consume
+ * (video/analysis/regions.py:159-174) -- is bound by HBM stores, the stages before it by VALU and
+ * latency.  With enable != 0 va_pipeline_run enqueues that write on a stream the pipeline owns, ordered
+ * after the labelling, and returns; the next va_pipeline_run starts its background / blur / morphology /
+ * labelling stages on the caller's stream at once, beside it (mask buffers and run tables exist twice).
+ * Contract while enabled: labels_out / stats_out of a run are complete on a stream only after
+ * va_pipeline_fence(p, that stream) (or a device synchronisation); counts_out / mask_out /
+ * filtered_out stay ordered on the run's own stream as before.  A caller that hands consecutive runs
+ * the same labels_out / stats_out buffer stays correct (the run's labelling stage then waits for the
+ * previous write); alternate two buffers to overlap that stage as well.
+ * va_pipeline_overlap synchronises the device; it allocates the second buffer set on first use. */
+int va_pipeline_overlap(va_pipeline_t *p, int enable);
+/* make `stream` wait for every label-image write this pipeline has enqueued so far (asynchronous:
+ * enqueues waits, never blocks the host) */
+int va_pipeline_fence(va_pipeline_t *p, void *stream);
 /* background-model state, so that a shard can start mid-video (SURVEY.md 5 "checkpoint") */
 int va_bg_get_state(va_pipeline_t *p, void *state_host, size_t bytes, int64_t *n_seen);
 int va_bg_set_state(va_pipeline_t *p, const void *state_host, size_t bytes, int64_t n_seen);

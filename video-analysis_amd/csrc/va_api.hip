@@ -5,6 +5,7 @@
 // thread-local message returned by va_last_error().
 #include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <new>
@@ -92,9 +93,22 @@ struct va_pipeline {
     void *blur;        // blurred frames when the caller does not ask for them (generic path)
     void *gscratch;    // generic Gaussian scratch (u16 / f32) or the planes of the re-laid-out u8 blur
     int planes_wp;     // > 0: u8 blur through reflected-padded single-channel planes of this width
-    uint32_t *bits[2];
-    void *ccl_ws;
+    // Mask ping-pong and labelling workspace exist twice ("slots") once va_pipeline_overlap is on: the
+    // paint pass of batch k reads slot k % 2 on the side stream while the stages of batch k + 1 fill the
+    // other one.  slot 1 is allocated by va_pipeline_overlap.
+    uint32_t *bits[2][2];
+    void *ccl_ws[2];
     size_t ccl_ws_bytes;
+    size_t bits_bytes;
+    bool overlap;
+    int slot;                       // slot of the next overlapped run
+    hipStream_t side;               // paint passes of overlapped runs
+    int paint_grid;                 // workgroups of the persistent paint pass of overlapped runs (0: one per row block)
+    hipEvent_t ev_front;            // labelling of the current batch done (main stream)
+    hipEvent_t ev_paint[2];         // paint pass that read slot s done (side stream)
+    bool paint_pending[2];          // ev_paint[s] has been recorded and may still be running
+    const char *paint_lo[2], *paint_hi[2];     // label image written by that paint pass
+    const char *pstat_lo[2], *pstat_hi[2];     // statistics written by that paint pass
     int32_t *labels_scratch;
     int32_t *counts_scratch;
     TapsQ8 tq;
@@ -779,11 +793,19 @@ int va_contour_moments(const void *points, const int32_t *npoints, int n, int ma
 // ------------------------------------------------------------------------------ pipeline
 static int pipeline_free(va_pipeline *p)
 {
-    void *ptrs[] = {p->bg_state, p->bg_state_alt, p->bg_recip, p->diff, p->blur, p->gscratch, p->bits[0], p->bits[1],
-                    p->ccl_ws,   p->labels_scratch, p->counts_scratch};
+    void *ptrs[] = {p->bg_state, p->bg_state_alt, p->bg_recip, p->diff, p->blur, p->gscratch,
+                    p->bits[0][0], p->bits[0][1], p->bits[1][0], p->bits[1][1],
+                    p->ccl_ws[0], p->ccl_ws[1], p->labels_scratch, p->counts_scratch};
     for (void *q : ptrs)
         if (q)
             (void)hipFree(q);
+    if (p->side)
+        (void)hipStreamDestroy(p->side);
+    if (p->ev_front)
+        (void)hipEventDestroy(p->ev_front);
+    for (hipEvent_t e : p->ev_paint)
+        if (e)
+            (void)hipEventDestroy(e);
     if (p->prof) {
         for (int i = 0; i < StageProfiler::kMaxMarks; i++)
             if (p->prof->created[i])
@@ -911,11 +933,12 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
     }
     if (masks) {
         size_t bb = align_up(nb * cfg->height * p->w32 * sizeof(uint32_t));
-        PIPE_MALLOC(p->bits[0], bb);
-        PIPE_MALLOC(p->bits[1], bb);
+        p->bits_bytes = bb;
+        PIPE_MALLOC(p->bits[0][0], bb);
+        PIPE_MALLOC(p->bits[0][1], bb);
         if (cfg->connectivity) {
             p->ccl_ws_bytes = ccl_rows_workspace_bytes(cfg->max_batch, cfg->height);
-            PIPE_MALLOC(p->ccl_ws, p->ccl_ws_bytes);
+            PIPE_MALLOC(p->ccl_ws[0], p->ccl_ws_bytes);
             PIPE_MALLOC(p->counts_scratch, align_up(nb * sizeof(int32_t)));
             // forest / label scratch for runs that do not ask for the label image (counts only:
             // sparse forest words, never painted; stats only: painted here).  Allocated now so
@@ -951,6 +974,74 @@ int va_pipeline_destroy(va_pipeline_t *p)
 }
 
 const char *va_pipeline_describe(const va_pipeline_t *p) { return p ? p->desc : ""; }
+
+int va_pipeline_overlap(va_pipeline_t *p, int enable)
+{
+    VA_ENTER();
+    VA_REQUIRE(p, "va_pipeline_overlap: NULL pipeline");
+    VA_HIP(hipDeviceSynchronize());                  // no paint pass in flight across the switch
+    p->paint_pending[0] = p->paint_pending[1] = false;
+    p->slot = 0;
+    if (!enable) {
+        p->overlap = false;
+        return VA_OK;
+    }
+    VA_REQUIRE(p->cfg.thresh >= 0 && p->cfg.connectivity,
+               "va_pipeline_overlap: only a labelling pipeline has a paint pass to overlap");
+#define OV_MALLOC(ptr, bytes)                                                               \
+    do {                                                                                    \
+        if (!(ptr)) {                                                                       \
+            hipError_t _e = hipMalloc((void **)&(ptr), (bytes));                            \
+            if (_e != hipSuccess) {                                                         \
+                (ptr) = nullptr;                                                            \
+                set_error("va_pipeline_overlap: hipMalloc(%zu) failed: %s", (size_t)(bytes), \
+                          hipGetErrorString(_e));                                           \
+                return VA_ERR_NOMEM;                                                        \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
+    OV_MALLOC(p->bits[1][0], p->bits_bytes);
+    OV_MALLOC(p->bits[1][1], p->bits_bytes);
+    OV_MALLOC(p->ccl_ws[1], p->ccl_ws_bytes);
+#undef OV_MALLOC
+    if (!p->side) {
+        // lowest priority: the dispatcher places the workgroups of the caller's stream (VALU-/latency-
+        // bound kernels with large register and LDS footprints) first, and the paint pass -- tens of
+        // thousands of small store-only workgroups that would otherwise take every slot that frees
+        // up -- fills what is left of the CUs and of the HBM bandwidth.  enable == 2: default priority
+        // (kept for A/B measurements).
+        int lo = 0, hi = 0;
+        VA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));        // lo = numerically greatest = least urgent
+        VA_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, enable == 2 ? 0 : lo));
+    }
+    if (!p->ev_front)
+        VA_HIP(hipEventCreateWithFlags(&p->ev_front, hipEventDisableTiming));
+    for (int s = 0; s < 2; s++)
+        if (!p->ev_paint[s])
+            VA_HIP(hipEventCreateWithFlags(&p->ev_paint[s], hipEventDisableTiming));
+    {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device);
+        // persistent paint pass, 4 workgroups per CU: bounded footprint beside the next batch's kernels
+        // (measured best of 0 = one workgroup per row block, 1, 2, 4, 8: tools/overlap_probe.py);
+        // $VA_PAINT_WGS_PER_CU overrides it for such measurements
+        const char *e = getenv("VA_PAINT_WGS_PER_CU");
+        const int per_cu = e ? atoi(e) : 4;
+        p->paint_grid = per_cu > 0 ? ((cus * per_cu + 7) / 8) * 8 : 0;
+    }
+    p->overlap = true;
+    return VA_OK;
+}
+
+int va_pipeline_fence(va_pipeline_t *p, void *stream)
+{
+    VA_ENTER();
+    VA_REQUIRE(p, "va_pipeline_fence: NULL pipeline");
+    for (int s = 0; s < 2; s++)
+        if (p->paint_pending[s])
+            VA_HIP(hipStreamWaitEvent(as_stream(stream), p->ev_paint[s], 0));
+    return VA_OK;
+}
 
 size_t va_bg_state_bytes(const va_pipeline_t *p) { return p ? p->bg_bytes : 0; }
 
@@ -1056,12 +1147,21 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
         VA_MARK("bg");
     }
 
+    // Overlapped runs (va_pipeline_overlap): this batch's masks and run tables live in slot `slot`; the
+    // paint pass that last read that slot (two runs ago) must be done before anything writes it.
+    const bool want_ccl = masks && c.connectivity && (labels_out || counts_out || stats_out);
+    const bool defer_paint = p->overlap && want_ccl && (labels_out != nullptr || stats_out != nullptr);
+    const int slot = defer_paint ? p->slot : 0;
+    if (p->overlap && p->paint_pending[slot])
+        VA_HIP(hipStreamWaitEvent(st, p->ev_paint[slot], 0));
+    uint32_t *const *bits = p->bits[slot];
+
     // 2. Gaussian blur (+ threshold + bit packing when fused)
     bool have_bits = false;
     if (c.sigma > 0) {
         if (c.dtype == VA_U8 && p->fused) {
             rc = (p->mfma ? launch_gauss_mfma_u8 : launch_gauss_fused_u8)(
-                (const uint8_t *)cur, (uint8_t *)filtered_out, masks ? p->bits[0] : nullptr,
+                (const uint8_t *)cur, (uint8_t *)filtered_out, masks ? bits[0] : nullptr,
                 c.thresh, n, c.height, c.width, p->tq, st);
             if (rc)
                 return rc;
@@ -1101,19 +1201,18 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     // 3. threshold -> bit mask
     int b = 0;
     if (!have_bits) {
-        rc = launch_pack_bits((const uint8_t *)cur, p->bits[0], n, c.height, c.width, c.thresh, st);
+        rc = launch_pack_bits((const uint8_t *)cur, bits[0], n, c.height, c.width, c.thresh, st);
         if (rc)
             return rc;
         VA_MARK("threshold_pack");
     }
     // 4. morphology on bits (one fused kernel when the sequence allows it)
-    const bool want_ccl = c.connectivity && (labels_out || counts_out || stats_out);
     int32_t *labels = nullptr;
     if (want_ccl) {
         labels = labels_out ? labels_out : p->labels_scratch;
     }
     if (c.morph_count > 0 && morph_fused_supported(c.width, p->se, c.morph_count)) {
-        rc = launch_morph_fused(p->bits[b], p->bits[b ^ 1], n, c.height, c.width, c.morph_op, p->se,
+        rc = launch_morph_fused(bits[b], bits[b ^ 1], n, c.height, c.width, c.morph_op, p->se,
                                 c.morph_count, st);
         if (rc)
             return rc;
@@ -1121,7 +1220,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
         VA_MARK("morph_fused");
     } else {
         for (int i = 0; i < c.morph_count; i++) {
-            rc = launch_morph_bits(p->bits[b], p->bits[b ^ 1], n, c.height, c.width, c.morph_op[i],
+            rc = launch_morph_bits(bits[b], bits[b ^ 1], n, c.height, c.width, c.morph_op[i],
                                    p->se[i], st);
             if (rc)
                 return rc;
@@ -1130,7 +1229,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
         }
     }
     if (mask_out) {
-        rc = launch_unpack_bits(p->bits[b], mask_out, n, c.height, c.width, c.maxval, st);
+        rc = launch_unpack_bits(bits[b], mask_out, n, c.height, c.width, c.maxval, st);
         if (rc)
             return rc;
         VA_MARK("mask_unpack");
@@ -1140,11 +1239,45 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
         // counts alone come out of the labelling kernels; the label image (the chain's largest
         // write) is painted only for callers that read it or the per-label statistics
         const bool paint = labels_out != nullptr || stats_out != nullptr;
-        rc = launch_ccl(p->bits[b], labels, counts_out ? counts_out : p->counts_scratch, n,
-                        c.height, c.width, c.connectivity, p->ccl_ws, p->ccl_ws_bytes, stats_out,
-                        c.max_labels, st, prof, paint);
-        if (rc)
-            return rc;
+        int32_t *counts = counts_out ? counts_out : p->counts_scratch;
+        // The labelling kernels may write the label image (sparse forest words: chip-wide passes,
+        // frames beyond the LDS run table); a paint pass still in flight on the side stream that
+        // writes the same image -- the caller reuses one label buffer for consecutive batches --
+        // has to finish first.  Callers that alternate two label buffers never wait here.
+        const char *lo = (const char *)labels, *hi = lo + (size_t)n * p->frame_px * sizeof(int32_t);
+        const char *slo = (const char *)stats_out,
+                   *shi = slo + (stats_out ? (size_t)n * c.max_labels * VA_STATS_STRIDE * sizeof(int64_t) : 0);
+        for (int s = 0; s < 2 && p->overlap; s++)
+            if (p->paint_pending[s] &&
+                ((lo < p->paint_hi[s] && p->paint_lo[s] < hi) || (slo < p->pstat_hi[s] && p->pstat_lo[s] < shi)))
+                VA_HIP(hipStreamWaitEvent(st, p->ev_paint[s], 0));
+        if (!defer_paint) {
+            rc = launch_ccl(bits[b], labels, counts, n, c.height, c.width, c.connectivity, p->ccl_ws[0],
+                            p->ccl_ws_bytes, stats_out, c.max_labels, st, prof, paint);
+            if (rc)
+                return rc;
+        } else {
+            CclPaintPlan plan;
+            rc = launch_ccl_front(bits[b], labels, counts, n, c.height, c.width, c.connectivity, p->ccl_ws[slot],
+                                  p->ccl_ws_bytes, stats_out, c.max_labels, st, prof, &plan);
+            if (rc)
+                return rc;
+            VA_HIP(hipEventRecord(p->ev_front, st));
+            VA_HIP(hipStreamWaitEvent(p->side, p->ev_front, 0));
+            if (prof)
+                prof->mark(nullptr, p->side);            // (start of the side stream's part of this run)
+            plan.persistent_grid = p->paint_grid;
+            rc = launch_ccl_paint(plan, p->side, prof);
+            if (rc)
+                return rc;
+            VA_HIP(hipEventRecord(p->ev_paint[slot], p->side));
+            p->paint_pending[slot] = true;
+            p->paint_lo[slot] = lo;
+            p->paint_hi[slot] = hi;
+            p->pstat_lo[slot] = slo;
+            p->pstat_hi[slot] = shi;
+            p->slot = slot ^ 1;
+        }
     }
 #undef VA_MARK
     return VA_OK;
@@ -1177,7 +1310,8 @@ int va_pipeline_stage_times(va_pipeline_t *p, int capacity, char *names, double 
     if (!p->prof || p->prof->n == 0)
         return VA_OK;
     StageProfiler &pr = *p->prof;
-    VA_HIP(hipEventSynchronize(pr.ev[pr.n - 1]));
+    for (int i = 0; i < pr.n; i++)                  // (marks of overlapped runs sit on two streams)
+        VA_HIP(hipEventSynchronize(pr.ev[i]));
     int ns = 0;
     for (int i = 1; i < pr.n; i++) {
         if (!pr.name[i])

@@ -111,11 +111,11 @@ struct RowCtx {
     size_t row;  // f*h + y
 };
 
-__device__ __forceinline__ RowCtx row_ctx(int h, size_t total_rows)
+__device__ __forceinline__ RowCtx row_ctx(int h, size_t total_rows, unsigned block = blockIdx.x)
 {
     RowCtx c;
     c.lane = threadIdx.x & (kWave - 1);
-    c.row = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    c.row = (size_t)block * kRowsPerBlock + (threadIdx.x >> 6);
     c.valid = c.row < total_rows;
     size_t r = c.valid ? c.row : 0;
     c.f = (int)(r / h);
@@ -1197,13 +1197,19 @@ __global__ void __launch_bounds__(kBlock)
 ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
                  int w32, size_t total_rows, int64_t *__restrict__ stats, int max_labels,
                  int vec_ok, const int32_t *__restrict__ table, int table_stride,
-                 const int32_t *__restrict__ rowbase_g, const int32_t *__restrict__ mode, int xcd_frames)
+                 const int32_t *__restrict__ rowbase_g, const int32_t *__restrict__ mode, int xcd_frames,
+                 int vblocks)
 {
+    // vblocks = row blocks to paint.  gridDim.x == vblocks: one per workgroup; a smaller grid (a
+    // multiple of 8, so that a workgroup's blocks stay on its XCD's frames) walks them with stride
+    // gridDim.x -- the persistent form used when the pass runs beside other kernels
+    // (va_pipeline_overlap): its footprint on a CU is then bounded by the grid, not by what is free.
     __shared__ uint32_t s_m[kRowsPerBlock][kWave];
     __shared__ uint32_t s_heads[kRowsPerBlock][kWave];
     __shared__ int32_t s_lab[kRowsPerBlock][kWave][16];
 
-    RowCtx c = row_ctx(h, total_rows);
+    for (int vb = blockIdx.x; vb < vblocks; vb += gridDim.x) {
+    RowCtx c = row_ctx(h, total_rows, (unsigned)vb);
 #ifdef VA_CCL_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 16)
         g_ccl_xcc[1][blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
@@ -1213,7 +1219,7 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         // labelling kernel ran frame f on XCD f % 8 (one workgroup per frame), so the run table, the
         // row bases and the mask rows of a frame are still in THAT XCD's L2: give every XCD the rows
         // of its own frames (frames come in groups of 8; xcd_frames = blocks per frame)
-        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int xcd = vb & 7, q = vb >> 3;
         const int fr = (q / xcd_frames) * 8 + xcd;
         const int rb = (q % xcd_frames) * kRowsPerBlock + (threadIdx.x >> 6);
         c.f = fr;
@@ -1367,6 +1373,7 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         if (w0 + kWave < w32)          // (a barrier after the last chunk would only hold the wave until its
             __syncthreads();           // stores are acknowledged)
     }
+    }   // vb
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1683,10 +1690,16 @@ size_t ccl_workspace_bytes(int n, int h, int w)
 }
 
 // workspace here = row_cnt + row_off only (the caller owns the bit mask)
-int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
-               int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
-               hipStream_t st, StageProfiler *prof, bool paint)
+// The labelling proper: everything up to (not including) the write of the label image.  `plan`
+// (nullable: nobody will paint) receives what launch_ccl_paint needs, so that the caller may run the
+// store-bound paint pass on another stream, beside the next batch's VALU-bound stages.
+int launch_ccl_front(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
+                     int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
+                     hipStream_t st, StageProfiler *prof, CclPaintPlan *plan)
 {
+    const bool paint = plan != nullptr;
+    if (plan)
+        plan->n = 0;                             // (nothing to paint until the front has been enqueued)
 #define VA_MARK(nm)      \
     do {                 \
         if (prof)        \
@@ -1710,7 +1723,6 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     int32_t *frame_mode = (int32_t *)((char *)run_table + up((size_t)n * kFrameLdsWords * sizeof(int32_t)));
     bool table_mode = false;                 // set when the per-frame kernel hands its labels over as tables
     int table_stride = 0;
-    const int grid = cdiv((long long)total_rows, kRowsPerBlock);          // paint: wave = row
 
     const dim3 sgrid_all((unsigned)cdiv(h, kSparseRowsPerBlock), (unsigned)min(n, 4096));
     FrameList all{nullptr, nullptr, n};
@@ -1771,29 +1783,69 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
     }
     if (!paint)
         return VA_OK;
-    const int vec = (w % 4 == 0) && aligned(labels, 16);
     // frames follow the XCD of their labelling workgroup when the per-frame kernel ran (see the kernel)
-    const int bpf = cdiv(h, kRowsPerBlock);
-    const int xcd_frames = table_mode ? bpf : 0;
-    const int pgrid = xcd_frames ? 8 * bpf * cdiv(n, 8) : grid;
-    if (stats && max_labels > 0) {
-        size_t entries = (size_t)n * max_labels;
+    plan->bits = bits;
+    plan->labels = labels;
+    plan->n = n;
+    plan->h = h;
+    plan->w = w;
+    plan->stats = stats;
+    plan->max_labels = max_labels;
+    plan->run_table = table_mode ? run_table : nullptr;
+    plan->table_stride = table_stride;
+    plan->row_off = row_off;
+    plan->frame_mode = frame_mode;
+    plan->xcd_frames = table_mode ? cdiv(h, kRowsPerBlock) : 0;
+    plan->persistent_grid = 0;
+#undef VA_MARK
+    return VA_OK;
+}
+
+int launch_ccl_paint(const CclPaintPlan &pl, hipStream_t st, StageProfiler *prof)
+{
+#define VA_MARK(nm)      \
+    do {                 \
+        if (prof)        \
+            prof->mark(nm, st); \
+    } while (0)
+    if (pl.n <= 0)
+        return VA_OK;
+    const int n = pl.n, h = pl.h, w = pl.w, w32 = words_per_row(pl.w);
+    const size_t total_rows = (size_t)n * h;
+    const int vec = (w % 4 == 0) && aligned(pl.labels, 16);
+    const int grid = cdiv((long long)total_rows, kRowsPerBlock);          // paint: wave = row
+    const int vblocks = pl.xcd_frames ? 8 * pl.xcd_frames * cdiv(n, 8) : grid;
+    const int pgrid = pl.persistent_grid > 0 ? min(vblocks, pl.persistent_grid) : vblocks;
+    if (pl.stats && pl.max_labels > 0) {
+        size_t entries = (size_t)n * pl.max_labels;
         stats_init_kernel<<<cdiv((long long)entries * VA_STATS_STRIDE, kBlock), kBlock, 0, st>>>(
-            stats, entries, h, w);
+            pl.stats, entries, h, w);
         VA_LAUNCH_CHECK("stats_init_kernel");
         VA_MARK("stats_init");
-        ccl_paint_kernel<true><<<pgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows, stats,
-                                                        max_labels, vec, table_mode ? run_table : nullptr,
-                                                        table_stride, row_off, frame_mode, xcd_frames);
+        ccl_paint_kernel<true><<<pgrid, kBlock, 0, st>>>(pl.bits, pl.labels, h, w, w32, total_rows, pl.stats,
+                                                        pl.max_labels, vec, pl.run_table, pl.table_stride,
+                                                        pl.row_off, pl.frame_mode, pl.xcd_frames, vblocks);
     } else {
-        ccl_paint_kernel<false><<<pgrid, kBlock, 0, st>>>(bits, labels, h, w, w32, total_rows,
-                                                         nullptr, 0, vec, table_mode ? run_table : nullptr,
-                                                         table_stride, row_off, frame_mode, xcd_frames);
+        ccl_paint_kernel<false><<<pgrid, kBlock, 0, st>>>(pl.bits, pl.labels, h, w, w32, total_rows, nullptr, 0,
+                                                         vec, pl.run_table, pl.table_stride, pl.row_off,
+                                                         pl.frame_mode, pl.xcd_frames, vblocks);
     }
     VA_LAUNCH_CHECK("ccl_paint_kernel");
     VA_MARK("ccl_paint");
 #undef VA_MARK
     return VA_OK;
+}
+
+int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
+               int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
+               hipStream_t st, StageProfiler *prof, bool paint)
+{
+    CclPaintPlan plan;
+    int rc = launch_ccl_front(bits, labels, counts, n, h, w, connectivity, workspace, ws_bytes, stats, max_labels,
+                              st, prof, paint ? &plan : nullptr);
+    if (rc || !paint)
+        return rc;
+    return launch_ccl_paint(plan, st, prof);
 }
 
 int launch_stats_from_labels(const int32_t *labels, int n, int h, int w, int max_labels,

@@ -202,6 +202,23 @@ int launch_ccl(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, in
                int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
                hipStream_t st, StageProfiler *prof = nullptr,
                bool paint = true);
+// the same in two halves: the labelling itself, and the write of the label image (+ per-label
+// statistics), which reads only what the plan names -- the final bit mask, the run tables in the
+// workspace (or the sparse forest words in the label image) -- and may run on another stream
+struct CclPaintPlan {
+    const uint32_t *bits;
+    int32_t *labels;
+    int n, h, w;          // n == 0: nothing to paint
+    int64_t *stats;
+    int max_labels;
+    const int32_t *run_table, *row_off, *frame_mode;
+    int table_stride, xcd_frames;
+    int persistent_grid;   // > 0: paint with this many workgroups (multiple of 8), each walking several row blocks
+};
+int launch_ccl_front(const uint32_t *bits, int32_t *labels, int32_t *counts, int n, int h, int w,
+                     int connectivity, void *workspace, size_t ws_bytes, int64_t *stats, int max_labels,
+                     hipStream_t st, StageProfiler *prof, CclPaintPlan *plan);
+int launch_ccl_paint(const CclPaintPlan &plan, hipStream_t st, StageProfiler *prof = nullptr);
 // outer contour of the component with the largest contour area (8-connectivity), on a forest
 // prepared by launch_ccl(..., paint = false): roots hold -(label) at their first pixel
 int launch_largest_contour(const uint32_t *bits, const int32_t *forest, int n, int h, int w,

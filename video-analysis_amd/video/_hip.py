@@ -106,6 +106,8 @@ SIGNATURES = {
     "va_pipeline_create": (_i, [C.POINTER(va_config), C.POINTER(_vp)]),
     "va_pipeline_destroy": (_i, [_vp]),
     "va_pipeline_run": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "va_pipeline_overlap": (_i, [_vp, _i]),
+    "va_pipeline_fence": (_i, [_vp, _vp]),
     "va_bg_get_state": (_i, [_vp, _vp, _sz, C.POINTER(_i64)]),
     "va_bg_set_state": (_i, [_vp, _vp, _sz, _i64]),
     "va_bg_state_bytes": (_sz, [_vp]),

@@ -97,6 +97,17 @@ class FrameEngine(object):
         check(self._lib.va_pipeline_run(self._handle, frames_ptr, int(n), filtered_ptr, mask_ptr,
                                         labels_ptr, counts_ptr, stats_ptr, stream))
 
+    def overlap(self, enable=True):
+        """run the label-image write of batch k on the engine's own stream, beside the stages of batch
+        k + 1 (`run_device` only).  While on, labels / stats of a run are complete on a stream only
+        after `fence(stream)`; give consecutive runs alternating label buffers for the full effect."""
+        check(self._lib.va_pipeline_overlap(self._handle, 1 if enable else 0))
+        self._overlap = bool(enable)
+
+    def fence(self, stream=None):
+        """make `stream` wait for every label-image write enqueued so far (asynchronous)"""
+        check(self._lib.va_pipeline_fence(self._handle, stream))
+
     # ------------------------------------------------------------------ NumPy API
     def _buf(self, name, nbytes):
         b = self._dev.get(name)
@@ -147,6 +158,8 @@ class FrameEngine(object):
             ptr["stats"] = self._buf("stats", n * max(self.max_labels, 1) * _hip.STATS_STRIDE * 8)
         g = lambda k: ptr[k].ptr if k in ptr else None
         self.run_device(src.ptr, n, g("filtered"), g("mask"), g("labels"), g("counts"), g("stats"))
+        if getattr(self, "_overlap", False):
+            self.fence(None)                # the downloads below read what the side stream writes
         out = {}
         if "filtered" in want:
             out["filtered"] = ptr["filtered"].download(arr.shape, self.dtype)
