@@ -48,6 +48,7 @@ STAGE_BYTES_PER_PX = {
     "bg": 1 + 1,                 # u8 frame in, u8 difference out (f64 state amortised per batch)
     "gauss_fused": 1 + 1 / 8,    # u8 in, thresholded bit mask out
     "gauss_mfma": 1 + 1 / 8,     # the same contract on the matrix cores
+    "gauss_mfma_mask8": 1 + 1,   # u8 in, thresholded uint8 mask out (the chain that ends at the mask)
     "gauss_generic": 1 + 1,      # u8 in, u8 out (the u16 scratch round trip is NOT compulsory)
     "gauss_planes": 1 + 1,       # u8 in, u8 out through reflected-padded planes
     "threshold_pack": 1 + 1 / 8,

@@ -92,6 +92,27 @@ def test_cfg2_1080p_blur_threshold_mask_only(oracle):
     _check_bg_blur_crops(oracle, clip, out["filtered"], state, 5.0, 15)
 
 
+@pytest.mark.parametrize("shape,sigma,thresh,maxval", [((3, 97, 208), 5.0, 20, 255), ((2, 64, 64), 2.0, 100, 1),
+                                                       ((1, 200, 528), 3.0, 0, 7), ((2, 33, 1936), 5.0, 254, 255),
+                                                       ((1, 1080, 80), 1.0, 128, 200)])
+def test_mask_only_chain_writes_bytes_from_the_gaussian(oracle, shape, sigma, thresh, maxval):
+    """the chain that ends at the uint8 mask (no morphology, no labelling, no u8 blur requested):
+    the matrix-core Gaussian's epilogue writes the 0 / maxval bytes itself"""
+    rng = np.random.default_rng(shape[2] + thresh)
+    clip = rng.integers(0, 256, shape, dtype=np.uint8)
+    clip[0, :9, :] = 255
+    clip[-1, :, -20:] = 0
+    eng = _engine(size=(shape[2], shape[1]), max_batch=shape[0], sigma=sigma, thresh=thresh, maxval=maxval)
+    assert "mfma" in eng.description
+    eng.profile(True)
+    got = eng.run(clip, want=("mask",))["mask"]
+    stages = eng.stage_times()
+    eng.close()
+    assert "gauss_mfma_mask8" in stages and "mask_unpack" not in stages
+    ref = oracle.threshold_u8(oracle.gaussian_u8(clip, sigma), thresh, maxval)
+    assert np.array_equal(got, ref)
+
+
 def test_cfg4_4k_full_chain_both_labelling_paths(oracle):
     """BASELINE.json configs[3]: 3840x2160 uint8 full chain; one rank's shard of the 1024-frame
     batch (128 frames) through va_pipeline_run, with the library's labelling choice (per-frame

@@ -1159,10 +1159,24 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     // 2. Gaussian blur (+ threshold + bit packing when fused)
     bool have_bits = false;
     if (c.sigma > 0) {
+        if (c.dtype == VA_U8 && p->mfma && masks && mask_out && !filtered_out && c.morph_count == 0 && !want_ccl &&
+            reinterpret_cast<uintptr_t>(mask_out) % 4 == 0) {
+            // the chain ends at FilterThreshold's uint8 mask (BASELINE configs[1]): the Gaussian's
+            // epilogue writes the 0 / maxval bytes itself -- no bit mask, no unpack pass
+            rc = launch_gauss_mfma_u8((const uint8_t *)cur, mask_out, nullptr, c.thresh, n, c.height, c.width, p->tq,
+                                      st, c.maxval);
+            if (rc)
+                return rc;
+            VA_MARK("gauss_mfma_mask8");
+            return VA_OK;
+        }
         if (c.dtype == VA_U8 && p->fused) {
-            rc = (p->mfma ? launch_gauss_mfma_u8 : launch_gauss_fused_u8)(
-                (const uint8_t *)cur, (uint8_t *)filtered_out, masks ? bits[0] : nullptr,
-                c.thresh, n, c.height, c.width, p->tq, st);
+            if (p->mfma)
+                rc = launch_gauss_mfma_u8((const uint8_t *)cur, (uint8_t *)filtered_out, masks ? bits[0] : nullptr,
+                                          c.thresh, n, c.height, c.width, p->tq, st);
+            else
+                rc = launch_gauss_fused_u8((const uint8_t *)cur, (uint8_t *)filtered_out, masks ? bits[0] : nullptr,
+                                           c.thresh, n, c.height, c.width, p->tq, st);
             if (rc)
                 return rc;
             have_bits = masks;

@@ -128,8 +128,9 @@ int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int 
 // the same contract on the matrix cores (Toeplitz products with v_mfma_i32_32x32x32_i8):
 // taps <= 127, radius <= 16; preferred whenever it applies
 bool gauss_mfma_supported(int w, int h, const TapsQ8 &taps);
+// mask8_maxval > 0: dst receives the thresholded mask as bytes (maxval / 0) instead of the blur
 int launch_gauss_mfma_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,
-                         int h, int w, const TapsQ8 &taps, hipStream_t st);
+                         int h, int w, const TapsQ8 &taps, hipStream_t st, int mask8_maxval = 0);
 
 // recip_scratch: bg_scratch_bytes(n) bytes of device memory for the per-frame reciprocals of the
 // division-free running mean of batches above 256 frames (nullptr: the plain-division kernel is used);

@@ -55,6 +55,9 @@ constexpr int kLdsStride = kTileCols + 32 + 16;   // staged row: strip + halo + 
                                                   // -> ds_read_b128 of 32 rows is conflict free
 static_assert((kLdsStride / 16) % 2 == 1, "LDS row stride must be an odd multiple of 16 bytes");
 constexpr int kTapTable = 128;     // zero-padded tap table, tap i at [48 + i]
+#ifndef GMF_DST_AUX
+#define GMF_DST_AUX 0              // cache policy bits of the u8 output stores (2 = non-temporal)
+#endif
 constexpr int kFlushTiles = 8;     // mask words are written out every 8 output tiles
 constexpr int kFlushRows = 32 * kFlushTiles;
 static_assert(kFlushRows == kWaves * 64, "one thread per collected row at a flush");
@@ -70,17 +73,24 @@ __device__ __forceinline__ uint32_t bswap32(uint32_t v)
     return __builtin_amdgcn_perm(0u, v, 0x00010203u);
 }
 
-template <bool HAS_DST, bool HAS_BITS>
+// MASK8 (with HAS_DST): dst receives the thresholded mask as bytes, maxval where blur > thresh and 0
+// elsewhere (the chain that ends at FilterThreshold's uint8 mask: no bit mask, no unpack pass)
+template <bool HAS_DST, bool HAS_BITS, bool MASK8 = false>
 __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
     const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t *__restrict__ bits,
-    int thresh, int h, int w, int w32, int nstrips, int blocks_per_frame, int nframes, MfmaTaps tp)
+    int thresh, int h, int w, int w32, int nstrips, int blocks_per_frame, int nframes, MfmaTaps tp,
+    int maxval = 255)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[2][32 * kLdsStride];
     __shared__ int8_t s_taps[kTapTable];
     // outputs are collected in LDS and leave as 16-byte pieces: four-byte stores scattered over 32
     // rows per instruction cost this kernel 30 % (measured), although they add no HBM bytes
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[2][kFlushRows][kWaves];        // HAS_BITS
-    __shared__ __attribute__((aligned(16))) uint8_t s_dst[HAS_DST ? 2 : 1][HAS_DST ? 32 : 1][kTileCols];
+    // (row stride 33 words: the epilogue's word stores -- 32 lanes, one per tile row, same column --
+    //  fall on 32 different banks; with a 128-byte stride they all hit ONE bank, 32 LDS cycles per
+    //  store, which made the u8 output cost as much as the whole rest of the kernel)
+    constexpr int kDstStride = kTileCols / 4 + 1;
+    __shared__ uint32_t s_dst[HAS_DST ? 2 : 1][HAS_DST ? 32 : 1][kDstStride];
 
     // ---- start-up: zero-padded tap table in LDS (the only workgroup-wide step) -------------
     if (threadIdx.x < kTapTable) {
@@ -231,6 +241,13 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
         const v4i a0 = *reinterpret_cast<const v4i *>(cur_buf + frag_off);
         const v4i a1 = *reinterpret_cast<const v4i *>(cur_buf + frag_off + 32);
         v16i x = {};
+        // (u8 outputs: the tile the previous step's epilogue left in s_dst is read now and stored
+        //  further down, so that neither the LDS read nor the store sits at the end of a step)
+        v4i vout = {};
+        if (HAS_DST)
+#pragma unroll
+            for (int j = 0; j < 4; j++)                   // (four word reads: conflict free at this stride)
+                vout[j] = (int)s_dst[(t + 1) & 1][tid >> 3][(tid & 7) * 4 + j];
         x = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, brow[0], x, 0, 0, 0);
         x = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, brow[1], x, 0, 0, 0);
 
@@ -246,17 +263,26 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
                     p = __builtin_amdgcn_alignbit(p, (uint32_t)tv[i], 31);
             }
             const int u = t - 2;                               // output tile of this epilogue
+#ifndef GMF_NO_DST_LDS                                    // (ablation build: no byte conversion, no LDS gather)
             if (HAS_DST) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const uint32_t b0 = (uint32_t)(k_dst - tv[4 * g]) >> 16;
-                    const uint32_t b1 = (uint32_t)(k_dst - tv[4 * g + 1]) >> 16;
-                    const uint32_t b2 = (uint32_t)(k_dst - tv[4 * g + 2]) >> 16;
-                    const uint32_t b3 = (uint32_t)(k_dst - tv[4 * g + 3]) >> 16;
-                    *reinterpret_cast<uint32_t *>(&s_dst[u & 1][nn][32 * wave + 8 * g + 4 * hh]) =
-                        b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                    if (MASK8) {
+                        // |t| < 2^24, so t's top byte is 0xFF where t < 0 (blur > thresh) and 0 elsewhere:
+                        // three byte permutes collect four of them, one AND turns 0xFF into maxval
+                        const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)tv[4 * g + 1], (uint32_t)tv[4 * g], 0x0c0c0703u);
+                        const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)tv[4 * g + 3], (uint32_t)tv[4 * g + 2], 0x07030c0cu);
+                        s_dst[u & 1][nn][8 * wave + 2 * g + hh] = (t01 | t23) & (0x01010101u * (uint32_t)maxval);
+                    } else {
+                        // u8 blur: (acc + 2^15) >> 16, and acc + 2^15 = k_dst - t < 2^24: the result is byte 2
+                        const uint32_t d0 = (uint32_t)(k_dst - tv[4 * g]), d1 = (uint32_t)(k_dst - tv[4 * g + 1]);
+                        const uint32_t d2 = (uint32_t)(k_dst - tv[4 * g + 2]), d3 = (uint32_t)(k_dst - tv[4 * g + 3]);
+                        s_dst[u & 1][nn][8 * wave + 2 * g + hh] =
+                            __builtin_amdgcn_perm(d1, d0, 0x0c0c0602u) | __builtin_amdgcn_perm(d3, d2, 0x06020c0cu);
+                    }
                 }
             }
+#endif
             if (HAS_BITS) {
                 uint32_t wd = (p & 0xFu) | ((p & 0xF0u) << 4) | ((p & 0xF00u) << 8) | ((p & 0xF000u) << 12);
                 wd <<= 4 * hh;
@@ -272,6 +298,15 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
         //      of this step; its previous readers passed the last barrier), prefetch tile t+2 ------
         stage_write(next_buf, ga, gb);
         fetch(min(t + 2, ntiles), ga, gb);               // (a second register set, two steps ahead: 0.175 -> 0.188 ms)
+        if (HAS_DST) {                                    // output tile t-3 (after this step's loads: vmcnt retires in order)
+            const int us = t - 3, r = tid >> 3, c16 = (tid & 7) * 16, y = 32 * us + r;
+#ifdef GMF_NO_DST_STORE                                   // ablation build: every u8 store dropped by the hardware
+            const bool ok = false;
+#else
+            const bool ok = us >= 0 && y < h && xb + c16 < w;            // w % 16 == 0
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(vout, dst_rsrc, ok ? (uint32_t)(y * w + xb + c16) : kOob, 0, GMF_DST_AUX);
+        }
 
         // ---- accumulator -> two i8 operand fragments -----------------------------------------
         v4i cur_hi, cur_lo;
@@ -295,12 +330,6 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
         // ---- what the epilogues collected leaves as 16-byte pieces (other buffer than the next
         //      epilogue writes) ----------------------------------------------------------------------
         const int u = t - 2;
-        if (HAS_DST && u >= 0) {
-            const int r = tid >> 3, c16 = (tid & 7) * 16, y = 32 * u + r;
-            const bool ok = y < h && xb + c16 < w;                       // w % 16 == 0
-            const v4i v = *reinterpret_cast<const v4i *>(&s_dst[u & 1][r][c16]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, dst_rsrc, ok ? (uint32_t)(y * w + xb + c16) : kOob, 0, 0);
-        }
         if (HAS_BITS && u >= 0 && (u % kFlushTiles == kFlushTiles - 1 || u == ntiles - 1)) {
             const int g = u / kFlushTiles, y = g * kFlushRows + tid;
             const bool ok = y < h && tid < (u % kFlushTiles + 1) * 32;
@@ -315,6 +344,15 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gauss_mfma_kernel(
                                                           ok && xbw + k < w32 ? off + 4 * k : kOob, 0, 0);
             }
         }
+    }
+    if (HAS_DST) {                                        // the last output tile is still in s_dst
+        const int us = ntiles - 1, r = tid >> 3, c16 = (tid & 7) * 16, y = 32 * us + r;
+        const bool ok = y < h && xb + c16 < w;
+        v4i v;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            v[j] = (int)s_dst[us & 1][r][(tid & 7) * 4 + j];
+        __builtin_amdgcn_raw_buffer_store_b128(v, dst_rsrc, ok ? (uint32_t)(y * w + xb + c16) : kOob, 0, 0);
     }
 }
 
@@ -336,9 +374,11 @@ bool gauss_mfma_supported(int w, int h, const TapsQ8 &taps)
 }
 
 int launch_gauss_mfma_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,
-                         int h, int w, const TapsQ8 &taps, hipStream_t st)
+                         int h, int w, const TapsQ8 &taps, hipStream_t st, int mask8_maxval)
 {
     VA_REQUIRE(src && (dst || bits), "mfma gaussian: no output requested");
+    VA_REQUIRE(mask8_maxval <= 0 || (dst && !bits && thresh >= 0 && mask8_maxval <= 255),
+               "mfma gaussian: the byte-mask form writes dst only and needs a threshold");
     VA_REQUIRE(gauss_mfma_supported(w, h, taps), "mfma gaussian: unsupported kernel size %d",
                taps.ksize);
     VA_REQUIRE(reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
@@ -355,7 +395,10 @@ int launch_gauss_mfma_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int t
     const int nstrips = cdiv(w, 32), w32 = words_per_row(w);
     const int bpf = cdiv(w, kTileCols);
     dim3 grid((unsigned)(8 * cdiv(n, 8) * bpf));
-    if (dst && bits)
+    if (mask8_maxval > 0)
+        gauss_mfma_kernel<true, false, true><<<grid, kWaves * 64, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, bpf, n, tp,
+                                                                            mask8_maxval);
+    else if (dst && bits)
         gauss_mfma_kernel<true, true><<<grid, kWaves * 64, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, bpf, n, tp);
     else if (dst)
         gauss_mfma_kernel<true, false><<<grid, kWaves * 64, 0, st>>>(src, dst, bits, thresh, h, w, w32, nstrips, bpf, n, tp);
