@@ -157,11 +157,33 @@ def cpu_baseline_main(argv):
     import numpy as np
     from oracle import oracle as O
     path, sigma, thresh, morph, n1 = argv[0], float(argv[1]), int(argv[2]), int(argv[3]), int(argv[4])
+    check_path = argv[5] if len(argv) > 5 and argv[5] != "-" else None
     O.build()
     frames = np.load(path)
     n, h, w = frames.shape
+    timing = n1 > 0                                   # (0: only the check below)
     n1 = max(1, min(n1, n))
     cores = _cpu_count()
+    if check_path:
+        # what the GPU produced for the first k frames of one more (untimed) step, and the background
+        # state that step started from: the oracle must reproduce it bit for bit
+        ck = np.load(check_path)
+        k = int(ck["k"])
+        cmask, clabels, ccounts, _ = O.chain_u8(frames[:k], sigma, thresh, morph_ksize=morph,
+                                                connectivity=4 if morph else 0, mean=ck["state"],
+                                                n_seen=int(ck["n_seen"]), want_mask=True, want_labels=bool(morph))
+        chk = {"frames": k, "n_seen_before": int(ck["n_seen"])}
+        if morph:
+            chk["counts_equal"] = bool(np.array_equal(ccounts, ck["counts"]))
+            chk["labels_equal"] = bool(np.array_equal(clabels, ck["labels"]))
+            chk["objects"] = int(ccounts.sum())
+        else:
+            chk["mask_equal"] = bool(np.array_equal(cmask, ck["mask"]))
+            chk["foreground_px"] = int((cmask != 0).sum())
+        print("CPU_CHECK_JSON " + json.dumps(chk), flush=True)
+    if not timing:
+        print("CPU_BASELINE_JSON " + json.dumps({"value": None, "skipped": True}), flush=True)
+        return
     # -- 1 thread, the first n1 frames
     t0 = time.perf_counter()
     mask, labels, counts, _ = O.chain_u8(frames[:n1], sigma, thresh, morph_ksize=morph, connectivity=4,
@@ -240,27 +262,51 @@ def cpu_baseline_f32_main(argv):
     print("CPU_BASELINE_JSON " + json.dumps(res), flush=True)
 
 
-def cpu_baseline(sample, child_args, mode="--cpu-baseline-child"):
+def cpu_baseline(sample, child_args, mode="--cpu-baseline-child", check=None):
     """times the CPU legs in a fresh child process (this one has initialised the GPU: no fork, no
-    exec here -- a plain subprocess), on a bounded sample saved to /dev/shm"""
+    exec here -- a plain subprocess), on a bounded sample saved to /dev/shm (or the default temp
+    directory when /dev/shm is too small).  `check`: arrays for the child's bit-for-bit comparison
+    of one GPU step with the oracle.  Returns (cpu_baseline object, check object or None); a child
+    that cannot run leaves an "error" entry instead of taking the GPU line down with it."""
     import subprocess
     import tempfile
     import numpy as np
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
-    fd, path = tempfile.mkstemp(suffix=".npy", prefix="va_bench_sample_", dir=shm)
-    os.close(fd)
+    need = sample.nbytes * 2 + (sum(np.asarray(v).nbytes for v in check.values()) if check else 0) + (64 << 20)
+    shm = None
+    if os.path.isdir("/dev/shm"):
+        try:
+            st = os.statvfs("/dev/shm")
+            if st.f_bavail * st.f_frsize > need:
+                shm = "/dev/shm"
+        except OSError:
+            shm = None
+    path = cpath = None
     try:
+        fd, path = tempfile.mkstemp(suffix=".npy", prefix="va_bench_sample_", dir=shm)
+        os.close(fd)
         np.save(path, sample)
+        extra = []
+        if check is not None:
+            cpath = path + ".check.npz"
+            np.savez(cpath, **check)
+            extra = [cpath]
         out = subprocess.run([sys.executable, os.path.abspath(__file__), mode, path] +
-                             [str(a) for a in child_args], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             [str(a) for a in child_args] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                              universal_newlines=True, timeout=900)
+        res, chk = None, None
         for line in out.stdout.splitlines():
             if line.startswith("CPU_BASELINE_JSON "):
-                return json.loads(line[len("CPU_BASELINE_JSON "):])
-        return {"value": None, "error": (out.stderr or out.stdout)[-400:]}
+                res = json.loads(line[len("CPU_BASELINE_JSON "):])
+            elif line.startswith("CPU_CHECK_JSON "):
+                chk = json.loads(line[len("CPU_CHECK_JSON "):])
+        if res is None:
+            res = {"value": None, "error": (out.stderr or out.stdout)[-400:]}
+        return res, chk
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[-300:])}, None
     finally:
-        for q in (path, path + ".diff.npy"):
-            if os.path.exists(q):
+        for q in (path, (path or "") + ".diff.npy", cpath):
+            if q and os.path.exists(q):
                 os.unlink(q)
 
 
@@ -325,8 +371,8 @@ def bench_f32(args, torch, device, dev_index, rank, world):
                      "frac_of_hbm_peak": round(alg * fps / 1e9 / HBM_PEAK_GBS, 5),
                      "stage_avg_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in stage.items()}}}
     if not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames_f32].cpu().numpy(), (sigma, rate),
-                                           "--cpu-baseline-f32-child")
+        res["cpu_baseline"], _ = cpu_baseline(frames[:args.cpu_frames_f32].cpu().numpy(), (sigma, rate),
+                                              "--cpu-baseline-f32-child")
     print(json.dumps(res), flush=True)
     eng.close()
 
@@ -378,6 +424,13 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=160, help="frames in the CPU baseline sample")
     ap.add_argument("--cpu-frames-f32", type=int, default=6, help="frames in the f32 CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle's check of one GPU step")
+    ap.add_argument("--check-frames", type=int, default=8, help="frames of one step the oracle recomputes")
+    ap.add_argument("--no-extra", action="store_true", help="skip the gauss_valu and e2e_pinned_h2d legs")
+    ap.add_argument("--gauss", default="mfma", choices=["mfma", "valu"],
+                    help="8-bit Gaussian of the chain: matrix cores (default) or the dot4/dot2 VALU kernel")
+    ap.add_argument("--overlap", action="store_true",
+                    help="label-image write of step k beside the stages of step k+1 (va_pipeline_overlap)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port for the self-launched ranks")
     ap.add_argument("--launcher", action="store_true",
                     help="go through the torch.distributed.run child launch even for --gpus 1")
@@ -432,26 +485,41 @@ def main():
         batch = args.batch
     frames = synth_batch(torch, device, w, h, batch, blobs, salt, seed=3 + rank)
     ccl = morph > 0               # BASELINE configs[1] / [0] stop at the thresholded mask
-    labels = torch.empty((batch, h, w), dtype=torch.int32, device=device) if ccl else None
+    overlap = bool(args.overlap) and ccl
+    # overlapped runs alternate two label buffers (the consumer of batch k reads one while batch
+    # k + 1 is painted into the other)
+    labels = [torch.empty((batch, h, w), dtype=torch.int32, device=device) for _ in range(2 if overlap else 1)] if ccl else None
     mask = None if ccl else torch.empty((batch, h, w), dtype=torch.uint8, device=device)
     counts = torch.zeros((batch,), dtype=torch.int32, device=device)
     steps_morph = (("dilate", "rect", morph), ("erode", "rect", morph)) if morph else ()
-    eng = FrameEngine(size=(w, h), max_batch=batch, background="mean", sigma=sigma, thresh=thresh,
-                      morphology=steps_morph, connectivity=4 if ccl else 0, device=dev_index)
+    from video import _hip
+    L = _hip.lib(dev_index)
+    if args.gauss == "valu":      # the north star's "no MFMA" form of the chain (same bits)
+        _hip.check(L.va_test_hook_gaussian_u8(1))
+    eng_kw = dict(size=(w, h), max_batch=batch, background="mean", sigma=sigma, thresh=thresh,
+                  morphology=steps_morph, connectivity=4 if ccl else 0, device=dev_index)
+    eng = FrameEngine(**eng_kw)
+    _hip.check(L.va_test_hook_gaussian_u8(0))
+    if overlap:
+        eng.overlap(True)
     stream = torch.cuda.current_stream(device)
 
-    def step():
+    def run_chain(e, i=0):
         if ccl:
-            eng.run_device(frames.data_ptr(), batch, None, None, labels.data_ptr(), counts.data_ptr(),
-                           None, stream.cuda_stream)
+            e.run_device(frames.data_ptr(), batch, None, None, labels[i % len(labels)].data_ptr(), counts.data_ptr(),
+                         None, stream.cuda_stream)
         else:
-            eng.run_device(frames.data_ptr(), batch, None, mask.data_ptr(), None, None, None,
-                           stream.cuda_stream)
+            e.run_device(frames.data_ptr(), batch, None, mask.data_ptr(), None, None, None, stream.cuda_stream)
+
+    def step(i=0):
+        run_chain(eng, i)
         if world > 1:       # the path's only exchange: object counts of every shard, RCCL over xGMI
             return gather_counts(counts if args.backend == "nccl" else counts.cpu(), world * batch)
         return counts
 
     def fence():
+        if overlap:
+            eng.fence(stream.cuda_stream)      # the label-image writes on the pipeline's own stream
         torch.cuda.synchronize(device)
         if distributed:
             dist.barrier()
@@ -460,17 +528,22 @@ def main():
     if world > 1:                 # communicator set-up is not a step: do it before any timing
         gather_counts(counts if args.backend == "nccl" else counts.cpu(), world * batch)
     fence()
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
     eng.profile(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        all_counts = step()
+    marks[0].record(stream)
+    for i in range(args.steps):
+        all_counts = step(i)
+        marks[i + 1].record(stream)           # per-step device time on the launch stream (median below)
     fence()
     dt = time.perf_counter() - t0
     stage = eng.stage_times()
     eng.profile(False)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -480,6 +553,7 @@ def main():
 
     total_frames = world * batch * args.steps
     fps = total_frames / dt
+    failed = False
     if rank == 0:
         px = w * h
         # frame in + int32 labels out + count (10 368 004 B @1080p), or + u8 mask out
@@ -494,6 +568,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "median_ms_per_step": round(median_ms, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -505,6 +580,8 @@ def main():
                                       "%dx%d dilate/erode + 4-connected labelling + object counts" % (morph, morph)
                                       if morph else "uint8 mask out (no morphology, no labelling)"),
                        "frames_per_step_per_gpu": batch, "engine": eng.description,
+                       "overlap": "label-image write of step k on the pipeline's own stream beside the stages of "
+                                  "step k+1 (two label buffers); stage times then overlap" if overlap else "off",
                        "world_size": dist.get_world_size() if distributed else 1,
                        "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed
                                   else "single process"},
@@ -514,13 +591,128 @@ def main():
                       "frac_of_hbm_peak_per_gpu": round(chain_bytes_per_frame * fps / world / 1e9 / HBM_PEAK_GBS, 5),
                       "stage_avg_ms": stage_ms},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(frames.cpu().numpy(), (sigma, thresh, morph, max(args.cpu_frames, 1)))
+        if world == 1:
+            # ---- everything below is outside the timed region ------------------------------------
+            # (1) one more step of the same call, from a known background state, for the oracle
+            check = None
+            if not args.no_check:
+                k = max(1, min(args.check_frames, batch))
+                state0, seen0 = eng.get_background()
+                run_chain(eng, args.steps)
+                fence()
+                check = {"k": np.int64(k), "state": state0, "n_seen": np.int64(seen0)}
+                if ccl:
+                    check["labels"] = labels[args.steps % len(labels)][:k].cpu().numpy()
+                    check["counts"] = counts[:k].cpu().numpy()
+                else:
+                    check["mask"] = mask[:k].cpu().numpy()
+            # (2) the device's own fill / copy rates on the chain's largest buffer (second denominator)
+            res["copy_ceiling_GBs"] = copy_ceiling(torch, L, _hip, stream, labels[0] if ccl else mask, frames)
+            res["roofline"]["frac_of_copy_ceiling"] = round(
+                res["roofline"]["achieved"] / max(res["copy_ceiling_GBs"]["fill"], 1e-9), 5)
+            # (3) the same chain with its Gaussian on the VALU (the north star's "no MFMA"), same bits
+            if args.gauss == "mfma" and "mfma" in eng.description and not args.no_extra:
+                res["gauss_valu"] = side_chain(torch, device, L, _hip, eng_kw, run_chain, fence, batch, valu=True)
+            # (4) PCIe-inclusive: frames in pinned host memory, counts back (never `value`)
+            if not args.no_extra:
+                res["e2e_pinned_h2d"] = e2e_leg(torch, frames, eng_kw, ccl)
+            # (5) CPU legs + the oracle's verdict on the step of (1), in a fresh child process
+            if not args.no_cpu_baseline or check is not None:
+                cpu, chk = cpu_baseline(frames.cpu().numpy(),
+                                        (sigma, thresh, morph, 0 if args.no_cpu_baseline else max(args.cpu_frames, 1)),
+                                        check=check)
+                if not args.no_cpu_baseline:
+                    res["cpu_baseline"] = cpu
+                if check is not None:
+                    res["check"] = chk if chk is not None else {"error": cpu.get("error", "the checker did not run")}
+                    failed = not chk or not all(v for kk, v in chk.items() if kk.endswith("_equal"))
         print(json.dumps(res), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if failed:
+        raise SystemExit("bench.py: the GPU step does not match the oracle (see \"check\")")
+
+
+def copy_ceiling(torch, L, _hip, stream, big, frames):
+    """plain device fill of, and copy into, the chain's largest output buffer: what the memory
+    system gives the simplest possible kernels on this box, GB/s (bytes written; the copy also
+    reads as many)"""
+    nbytes = big.numel() * big.element_size()
+    src = torch.empty_like(big)
+    out = {}
+    for name, fn in (("fill", lambda: L.va_memset(big.data_ptr(), 0, nbytes, stream.cuda_stream)),
+                     ("copy", lambda: L.va_memcpy_d2d(big.data_ptr(), src.data_ptr(), nbytes, stream.cuda_stream))):
+        best = None
+        for _ in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            _hip.check(fn())
+            b.record(stream)
+            b.synchronize()
+            ms = a.elapsed_time(b)
+            best = ms if best is None else min(best, ms)
+        out[name] = round(nbytes / (best * 1e-3) / 1e9, 1)
+    out["bytes"] = nbytes
+    out["note"] = "hipMemsetAsync / hipMemcpyAsync D2D on the label (mask) buffer, best of 4; copy moves 2x these bytes"
+    return out
+
+
+def side_chain(torch, device, L, _hip, eng_kw, run_chain, fence, batch, valu):
+    """the same workload through a second pipeline whose 8-bit Gaussian runs on the VALU"""
+    from video.engine import FrameEngine
+    _hip.check(L.va_test_hook_gaussian_u8(1 if valu else 0))
+    e2 = FrameEngine(**eng_kw)
+    _hip.check(L.va_test_hook_gaussian_u8(0))
+    for i in range(2):
+        run_chain(e2, i)
+    fence()
+    e2.profile(True)
+    t0 = time.perf_counter()
+    k = 5
+    for i in range(k):
+        run_chain(e2, i)
+    fence()
+    dt = time.perf_counter() - t0
+    st = e2.stage_times()
+    desc = e2.description
+    e2.close()
+    g = [v for kk, v in st.items() if kk.startswith("gauss")]
+    return {"value": round(batch * k / dt, 1), "unit": "frames/s", "steps": k, "engine": desc,
+            "gauss_ms": round(g[0][0] / max(g[0][1], 1), 4) if g else None}
+
+
+def e2e_leg(torch, frames, eng_kw, ccl):
+    """host frames (pinned, produced in place) -> H2D -> chain -> per-frame counts (or the mask) D2H,
+    three HIP streams, batches of 64: the PCIe-inclusive rate of the same workload"""
+    from video.engine import FrameEngine
+    from video.streaming import StreamedEngine
+    sub = 64
+    kw = dict(eng_kw)
+    kw["max_batch"] = sub
+    host = frames[:sub].cpu().numpy()
+    e = FrameEngine(**kw)
+    want = ("counts",) if ccl else ("mask",)
+    nb = 12
+    with StreamedEngine(e, want=want, slots=3, copy_results=False) as s:
+        for _ in range(3):
+            buf, _d = s.input_buffer()
+            buf[:sub] = host
+            s.submit(None, n=sub)
+        s.drain()
+        t0 = time.perf_counter()
+        got = 0
+        for _ in range(nb):
+            _b, done = s.input_buffer()
+            got += len(done) + len(s.submit(None, n=sub))
+        got += len(s.drain())
+        dt = time.perf_counter() - t0
+    e.close()
+    fps = nb * sub / dt
+    return {"value": round(fps, 1), "unit": "frames/s", "frames": nb * sub, "batch": sub, "out": "+".join(want),
+            "h2d_GBs": round(fps * host[0].nbytes / 1e9, 2),
+            "note": "video/streaming.py StreamedEngine, frames already in pinned host buffers; never `value`"}
 
 
 if __name__ == "__main__":

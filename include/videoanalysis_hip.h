@@ -360,6 +360,9 @@ int va_morph_bits_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int
  * staging the mask rows in LDS even where it could read its spans straight from global memory;
  * lds_runs > 0 caps the per-frame kernel's run table (frames above it take its large-frame mode) */
 int va_test_hook_labelling(int path, int lds_runs);
+/* force_valu != 0: pipelines created from now on run their 8-bit Gaussian in the LDS/VALU (dot4/dot2)
+ * kernel instead of the matrix-core one (same bits; bench.py times the chain both ways) */
+int va_test_hook_gaussian_u8(int force_valu);
 /* bit 0: every later float32 Gaussian of this process runs its column pass in the runtime-radius
  * kernel, also for the radii (r = 4, 8, ... 36) that have an unrolled one; bit 1: the same for the
  * row pass (compile-time-radius kernels exist for the same radii) */

@@ -424,6 +424,15 @@ int va_test_hook_labelling(int path, int lds_runs)
     return VA_OK;
 }
 
+// test / measurement hook: pipelines created while this is set run their 8-bit Gaussian on the VALU
+// (dot4/dot2 LDS kernel) instead of the matrix cores -- the north star's "no MFMA" form of the chain
+static int g_gauss_u8_valu = 0;
+int va_test_hook_gaussian_u8(int force_valu)
+{
+    g_gauss_u8_valu = force_valu != 0;
+    return VA_OK;
+}
+
 int va_test_hook_gaussian_f32(int generic_columns)
 {
     gauss_f32_test_hook(generic_columns);
@@ -888,7 +897,7 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
     if (cfg->sigma > 0) {
         if (cfg->dtype == VA_U8) {
             PIPE_TRY(gauss_taps_q8(cfg->sigma, &p->tq.ksize, p->tq.t, kMaxTaps));
-            p->mfma = cfg->channels == 1 && gauss_mfma_supported(cfg->width, cfg->height, p->tq);
+            p->mfma = cfg->channels == 1 && !g_gauss_u8_valu && gauss_mfma_supported(cfg->width, cfg->height, p->tq);
             p->fused = p->mfma ||
                        (cfg->channels == 1 && gauss_fused_supported(cfg->width, cfg->height, p->tq));
         } else {

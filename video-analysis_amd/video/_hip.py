@@ -117,6 +117,7 @@ SIGNATURES = {
     "va_gaussian_u8_generic": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "va_gaussian_u8_valu": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "va_test_hook_labelling": (_i, [_i, _i]),
+    "va_test_hook_gaussian_u8": (_i, [_i]),
     "va_test_hook_gaussian_f32": (_i, [_i]),
     "va_morph_bits_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "va_comm_unique_id": (_i, [_vp]),
