@@ -429,6 +429,15 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the gauss_valu and e2e_pinned_h2d legs")
     ap.add_argument("--gauss", default="mfma", choices=["mfma", "valu"],
                     help="8-bit Gaussian of the chain: matrix cores (default) or the dot4/dot2 VALU kernel")
+    ap.add_argument("--video", default="own", choices=["own", "shared"],
+                    help="own: every rank has its own clip (independent cameras; the default and the driver's form); "
+                         "shared: ONE clip cut into contiguous shards (video/sharding.py), see --bg-share")
+    ap.add_argument("--bg-share", default="static", choices=["static", "exact"],
+                    help="--video shared: static = background measured on the first 8 frames by rank 0, broadcast once; "
+                         "exact = cumulative running mean handed from shard to shard every step")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="--video shared: weak = clip of N x batch frames, strong = clip of batch frames in all")
+    ap.add_argument("--dump-counts", default="", help="rank 0 writes the gathered counts of the last step here (.npy)")
     ap.add_argument("--overlap", action="store_true",
                     help="label-image write of step k beside the stages of step k+1 (va_pipeline_overlap)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port for the self-launched ranks")
@@ -483,7 +492,20 @@ def main():
     w, h, batch, sigma, thresh, morph, blobs, salt = WORKLOADS[args.workload]
     if args.batch > 0:
         batch = args.batch
-    frames = synth_batch(torch, device, w, h, batch, blobs, salt, seed=3 + rank)
+    from video.sharding import background_handoff, broadcast_background, shard_range
+    shared = args.video == "shared"
+    if shared:
+        # one clip for all ranks (same seed everywhere), cut into contiguous shards
+        total = batch * (world if args.scaling == "weak" else 1)
+        full = synth_batch(torch, device, w, h, total, blobs, salt, seed=3)
+        fa, fb = shard_range(total, world, rank)
+        frames = full[fa:fb].contiguous()
+        first8 = full[:8].contiguous()
+        del full
+        batch = fb - fa
+    else:
+        total = batch * world
+        frames = synth_batch(torch, device, w, h, batch, blobs, salt, seed=3 + rank)
     ccl = morph > 0               # BASELINE configs[1] / [0] stop at the thresholded mask
     overlap = bool(args.overlap) and ccl
     # overlapped runs alternate two label buffers (the consumer of batch k reads one while batch
@@ -496,10 +518,22 @@ def main():
     L = _hip.lib(dev_index)
     if args.gauss == "valu":      # the north star's "no MFMA" form of the chain (same bits)
         _hip.check(L.va_test_hook_gaussian_u8(1))
-    eng_kw = dict(size=(w, h), max_batch=batch, background="mean", sigma=sigma, thresh=thresh,
-                  morphology=steps_morph, connectivity=4 if ccl else 0, device=dev_index)
+    eng_kw = dict(size=(w, h), max_batch=max(batch, 1), background="static" if shared and args.bg_share == "static" else "mean",
+                  sigma=sigma, thresh=thresh, morphology=steps_morph, connectivity=4 if ccl else 0, device=dev_index)
     eng = FrameEngine(**eng_kw)
     _hip.check(L.va_test_hook_gaussian_u8(0))
+    wire = device if args.backend == "nccl" else None
+
+    def advance_state(state, seen, clip):
+        """running-mean state after `clip`, the state update alone (va_bg_update, diff_out = NULL)"""
+        st = torch.from_numpy(np.ascontiguousarray(state, np.float64)).to(device)
+        _hip.check(L.va_bg_update(1, 0, clip.data_ptr(), None, st.data_ptr(), int(seen), 0.0, clip.shape[0], w * h,
+                                  torch.cuda.current_stream(device).cuda_stream))
+        return st.cpu().numpy()
+
+    if shared and args.bg_share == "static":
+        state = advance_state(np.zeros((h, w)), 0, first8) if rank == 0 else np.zeros((h, w))
+        eng.set_background(broadcast_background(state, src=0, device=wire), 0)
     if overlap:
         eng.overlap(True)
     stream = torch.cuda.current_stream(device)
@@ -512,9 +546,15 @@ def main():
             e.run_device(frames.data_ptr(), batch, None, mask.data_ptr(), None, None, None, stream.cuda_stream)
 
     def step(i=0):
+        if shared and args.bg_share == "exact":
+            # exact cumulative mean over the whole clip, every pass: rank r starts from the state after
+            # frames [0, start_r), handed on by rank r - 1 (which advanced it with the state update alone)
+            st0, seen0 = background_handoff(lambda st, sn: advance_state(st, sn, frames), (h, w), np.float64,
+                                            n_local=batch, device=wire)
+            eng.set_background(st0, seen0)
         run_chain(eng, i)
         if world > 1:       # the path's only exchange: object counts of every shard, RCCL over xGMI
-            return gather_counts(counts if args.backend == "nccl" else counts.cpu(), world * batch)
+            return gather_counts(counts if args.backend == "nccl" else counts.cpu(), total)
         return counts
 
     def fence():
@@ -526,7 +566,7 @@ def main():
         torch.cuda.synchronize(device)
 
     if world > 1:                 # communicator set-up is not a step: do it before any timing
-        gather_counts(counts if args.backend == "nccl" else counts.cpu(), world * batch)
+        gather_counts(counts if args.backend == "nccl" else counts.cpu(), total)
     fence()
     for i in range(args.warmup):
         step(i)
@@ -548,11 +588,13 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    if world > 1 and all_counts.numel() != world * batch:
-        raise SystemExit("count gather returned %d entries for %d frames" % (all_counts.numel(), world * batch))
+    if world > 1 and all_counts.numel() != total:
+        raise SystemExit("count gather returned %d entries for %d frames" % (all_counts.numel(), total))
 
-    total_frames = world * batch * args.steps
+    total_frames = total * args.steps
     fps = total_frames / dt
+    if args.dump_counts and rank == 0:
+        np.save(args.dump_counts, all_counts.cpu().numpy())
     failed = False
     if rank == 0:
         px = w * h
@@ -570,7 +612,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "median_ms_per_step": round(median_ms, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if shared else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
@@ -580,6 +622,10 @@ def main():
                                       "%dx%d dilate/erode + 4-connected labelling + object counts" % (morph, morph)
                                       if morph else "uint8 mask out (no morphology, no labelling)"),
                        "frames_per_step_per_gpu": batch, "engine": eng.description,
+                       "video": ("one clip of %d frames in contiguous shards, background %s" % (total, {
+                           "static": "measured on its first 8 frames by rank 0 and broadcast once",
+                           "exact": "= cumulative running mean handed from shard to shard every step"}[args.bg_share]))
+                                if shared else "one clip per rank",
                        "overlap": "label-image write of step k on the pipeline's own stream beside the stages of "
                                   "step k+1 (two label buffers); stage times then overlap" if overlap else "off",
                        "world_size": dist.get_world_size() if distributed else 1,
@@ -595,7 +641,7 @@ def main():
             # ---- everything below is outside the timed region ------------------------------------
             # (1) one more step of the same call, from a known background state, for the oracle
             check = None
-            if not args.no_check:
+            if not args.no_check and not shared:
                 k = max(1, min(args.check_frames, batch))
                 state0, seen0 = eng.get_background()
                 run_chain(eng, args.steps)
@@ -611,10 +657,10 @@ def main():
             res["roofline"]["frac_of_copy_ceiling"] = round(
                 res["roofline"]["achieved"] / max(res["copy_ceiling_GBs"]["fill"], 1e-9), 5)
             # (3) the same chain with its Gaussian on the VALU (the north star's "no MFMA"), same bits
-            if args.gauss == "mfma" and "mfma" in eng.description and not args.no_extra:
+            if args.gauss == "mfma" and "mfma" in eng.description and not args.no_extra and not shared:
                 res["gauss_valu"] = side_chain(torch, device, L, _hip, eng_kw, run_chain, fence, batch, valu=True)
             # (4) PCIe-inclusive: frames in pinned host memory, counts back (never `value`)
-            if not args.no_extra:
+            if not args.no_extra and not shared:
                 res["e2e_pinned_h2d"] = e2e_leg(torch, frames, eng_kw, ccl)
             # (5) CPU legs + the oracle's verdict on the step of (1), in a fresh child process
             if not args.no_cpu_baseline or check is not None:

@@ -52,3 +52,73 @@ def test_gather_counts_two_ranks_gloo(tmp_path, n_frames):
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         assert got.dtype == np.int32 and np.array_equal(got, full)      # frame order, every rank
+
+
+# ---------------------------------------------------------------------------- one video, several shards
+def _run_worker(tmp, world, extra):
+    """world 1: a plain child process; world 2: two fresh children through torch.distributed.run
+    (gloo; never an exec of this pytest process)"""
+    import subprocess
+    worker = os.path.join(ROOT, "tests", "shared_video_worker.py")
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "2")
+    if world == 1:
+        cmd = [sys.executable, worker]
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), worker]
+    out = subprocess.run(cmd + ["--out", str(tmp)] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         universal_newlines=True, timeout=600)
+    fails = [ln for ln in out.stdout.splitlines() if "FAILED" in ln or "Error" in ln]
+    assert out.returncode == 0, "\n".join(fails[:12]) + "\n...\n" + out.stdout[-1500:]
+
+
+def _assert_sharded_equals_single(tmp, n_frames, world=2):
+    from video.sharding import shard_range
+    single = np.load(os.path.join(str(tmp), "counts_world1.npy"))
+    sharded = np.load(os.path.join(str(tmp), "counts_world%d.npy" % world))
+    assert single.shape == (n_frames,) and single.max() >= 1
+    assert np.array_equal(single, sharded)                          # gathered counts, frame order, bit for bit
+    whole = np.load(os.path.join(str(tmp), "labels_world1_rank0.npy"))
+    for r in range(world):
+        a, b = shard_range(n_frames, world, r)
+        part = np.load(os.path.join(str(tmp), "labels_world%d_rank%d.npy" % (world, r)))
+        assert np.array_equal(part, whole[a:b]), "rank %d" % r       # and the label maps of every shard
+
+
+@pytest.mark.parametrize("bg", ["exact", "static"])
+def test_same_video_two_shards_equal_one_run_cpu_twin(tmp_path, oracle, bg):
+    """gathered counts (and label maps) of 2 shards of ONE clip == the single-rank
+    run of the same frames, with the running mean handed from shard to shard (exact) and with a static
+    background broadcast once.  CPU: per-op calls into the oracle behind the product's ABI."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvideoanalysis_cpu.so"],
+                          stdout=subprocess.DEVNULL)
+    extra = ["--lib", "cpu", "--bg", bg, "--frames", "13", "--size", "96x72"]       # ragged shards: 7 + 6
+    _run_worker(tmp_path, 1, extra)
+    _run_worker(tmp_path, 2, extra)
+    _assert_sharded_equals_single(tmp_path, 13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bg,engine", [("exact", False), ("exact", True), ("static", True)])
+def test_same_video_two_shards_equal_one_run_gpu(tmp_path, bg, engine):
+    """the same on the MI355X: 2 x 16 frames at 480p, two fresh child processes sharing the one card
+    (gloo for the host-side exchange), per-op calls and the fused pipeline; plus the C ABI's own
+    RCCL gather at world 2 -- accepted or refused by RCCL with two ranks on one device, the outcome
+    is printed (and checked when it succeeds)."""
+    extra = ["--lib", "hip", "--bg", bg, "--frames", "32", "--size", "640x480"] + (["--engine"] if engine else [])
+    _run_worker(tmp_path, 1, extra)
+    _run_worker(tmp_path, 2, extra + (["--comm"] if engine and bg == "exact" else []))
+    _assert_sharded_equals_single(tmp_path, 32)
+    if engine and bg == "exact":
+        single = np.load(os.path.join(str(tmp_path), "counts_world1.npy"))
+        for r in range(2):
+            note = open(os.path.join(str(tmp_path), "comm_world2_rank%d.txt" % r)).read().strip()
+            print("va_comm world 2, rank %d: %s" % (r, note[:300]))
+            if note.startswith("ok "):
+                assert [int(v) for v in note.split()[1:]] == single.tolist()

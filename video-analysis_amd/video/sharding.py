@@ -6,9 +6,18 @@ exchange is the final gather of the per-frame object counts (`gather_counts`), a
 `frames_per_rank` int32 over torch.distributed -- backend "nccl" (= RCCL over xGMI) on the
 GPUs, "gloo" in the CPU tests.
 
-The running-mean background is a temporal recurrence; each shard either starts from an exported
-state (`FrameEngine.get_background()` / `set_background()`, exact) or from its own first frame
-(independent cameras / clips).  bench.py uses the latter: one clip per rank.
+The running-mean background is a temporal recurrence (`mean*n/(n+1) + frame/(n+1)`,
+video/analysis/video.py:32-33), so the shards of ONE video share it in one of two ways:
+
+* `broadcast_background` -- a background computed beforehand (static model) goes from one rank to
+  all, once; every shard then differences against the same state (SURVEY.md 8e, option 1);
+* `background_handoff`   -- exact cumulative semantics: rank r receives (state, n_seen) as it stands
+  after frames [0, start_r), advances a copy over its own frames (state update only, the cheap
+  part of the chain) and passes it on to rank r + 1 BEFORE it runs its own chain, so only the
+  background passes of the shards serialise (option 3).  Gathered results then equal a single-GPU
+  run of the whole video bit for bit.
+
+Independent clips (one camera per rank) need neither; bench.py's default does that.
 """
 
 
@@ -55,3 +64,56 @@ def gather_counts(local_counts, n_frames=None, group=None):
     send[:local_counts.numel()] = local_counts
     dist.all_gather_into_tensor(recv, send, group=group)
     return torch.cat([recv[r * cap:r * cap + sizes[r]] for r in range(world)])
+
+
+def _to_wire(arr, device):
+    import torch
+    t = torch.from_numpy(arr)
+    return t.to(device) if device is not None else t
+
+
+def broadcast_background(state, src=0, device=None, group=None):
+    """every rank returns rank `src`'s background state (a float64/float32 NumPy array of the frame
+    shape; other ranks pass an array of the same shape and dtype, its content is ignored).
+    device: torch device the collective runs on (a cuda device for nccl = RCCL; None = CPU, gloo)."""
+    import numpy as np
+    import torch.distributed as dist
+
+    state = np.ascontiguousarray(state)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return state.copy()
+    t = _to_wire(state.copy(), device)
+    dist.broadcast(t, src=src, group=group)
+    return t.cpu().numpy()
+
+
+def background_handoff(advance, shape, dtype, first_state=None, first_seen=0, n_local=0, device=None,
+                       group=None):
+    """exact running-mean semantics across the shards of one video.
+
+    advance(state, n_seen) -> state after this rank's `n_local` frames (the state update alone, e.g.
+    va_bg_update with diff_out = NULL on the shard's frames; must not modify its argument).
+    Rank 0 starts from (`first_state` or zeros, `first_seen`); rank r > 0 blocks until rank r - 1 has
+    advanced.  Every rank returns the (state, n_seen) ITS chain has to start from.  The state moves as
+    one float tensor plus one int64 over point-to-point send/recv (gloo or nccl)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if rank == 0:
+        state = np.zeros(shape, dtype) if first_state is None else np.array(first_state, dtype).reshape(shape)
+        seen = int(first_seen)
+    else:
+        st = _to_wire(np.empty(shape, dtype), device)
+        sn = torch.zeros(1, dtype=torch.int64, device=st.device)
+        dist.recv(st, src=rank - 1, group=group)
+        dist.recv(sn, src=rank - 1, group=group)
+        state, seen = st.cpu().numpy(), int(sn.item())
+    if rank + 1 < world:
+        nxt = np.ascontiguousarray(advance(state, seen), dtype).reshape(shape)
+        st = _to_wire(nxt, device)
+        dist.send(st, dst=rank + 1, group=group)
+        dist.send(torch.tensor([seen + int(n_local)], dtype=torch.int64, device=st.device), dst=rank + 1, group=group)
+    return state, seen
