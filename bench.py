@@ -191,7 +191,7 @@ def cpu_baseline_main(argv):
     dt1 = time.perf_counter() - t0
     res = {"value": round(n1 / dt1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "%d of the batch's %dx%d frames, full chain incl. labelling, oracle/va_oracle.c "
-                     "gcc -O3 -march=native, 1 thread of %d usable host cores (os.cpu_count()=%d), %.1f s"
+                     "gcc -O3 -march=x86-64-v2, 1 thread of %d usable host cores (os.cpu_count()=%d), %.1f s"
                      % (n1, w, h, cores, os.cpu_count() or 0, dt1)}
     # -- all cores
     workers = max(1, min(cores, 64))

@@ -57,6 +57,13 @@ extern "C" {
 #define VA_BG_EMA 2    /* bg += rate*(frame-bg), float32 state (no reference counterpart)        */
 #define VA_BG_STATIC 3 /* fixed float64 background image (e.g. a measure_mean() result)          */
 /* morphology */
+/* which OpenCV's 8-bit Gaussian taps (both written from upstream knowledge, unverifiable offline):
+ * CV4: unsigned 8.8 fixed point with error diffusion, sum forced to 256 (OpenCV >= 4.x; default);
+ * CV3: float32 getGaussianKernel, every tap cvRound(k * 256) on its own, sum not forced -- OpenCV 2.4 / 3.x,
+ *      the era of the reference (cv2.findContours(...)[1], video/analysis/regions.py:180-182) */
+#define VA_TAPS_CV4 0
+#define VA_TAPS_CV3 1
+
 #define VA_MORPH_ERODE 0
 #define VA_MORPH_DILATE 1
 #define VA_SHAPE_RECT 0    /* cv2.MORPH_RECT    */
@@ -73,6 +80,10 @@ const char *va_version(void);
 const char *va_last_error(void);       /* message for the calling thread's last failure      */
 
 /* device memory helpers, so that a host without torch can drive the library */
+/* The stand-alone entry points lease their device scratch from the device's default memory pool,
+ * whose pages va_init keeps mapped between calls; va_trim hands everything above keep_bytes back to
+ * the device (synchronises it) -- e.g. before another library in the process needs the memory. */
+int va_trim(size_t keep_bytes);
 int va_malloc(void **dev_ptr, size_t bytes);
 int va_free(void *dev_ptr);
 int va_host_alloc(void **host_ptr, size_t bytes); /* pinned host memory */
@@ -105,8 +116,13 @@ int va_gaussian_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w
  * ksize = cvRound(8 sigma + 1)|1, float32 taps and fmaf accumulation. */
 int va_gaussian_f32(const float *src_dev, float *dst_dev, int n, int h, int w, int c,
                     double sigma, void *stream);
+/* the same with the tap set named explicitly (VA_TAPS_CV4 = va_gaussian_u8's, VA_TAPS_CV3 = the
+ * reference-era definition; same row/column arithmetic: integer row sums, (acc + 2^15) >> 16 saturated) */
+int va_gaussian_u8_rule(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w, int c,
+                        double sigma, int tap_rule, void *stream);
 /* analytic taps (host side, no GPU needed): q8.8 taps sum to 256 */
 int va_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps_out, int capacity);
+int va_gauss_taps_q8_rule(double sigma, int tap_rule, int *ksize_out, uint16_t *taps_out, int capacity);
 int va_gauss_taps_f32(double sigma, int *ksize_out, float *taps_out, int capacity);
 
 /* ------------------------------------------------------------------ A2 background model
@@ -292,13 +308,15 @@ typedef struct va_config {
     int32_t morph_ksize[VA_MAX_MORPH_OPS];
     int32_t connectivity; /* 0: no labelling, 4, 8 */
     int32_t max_labels;   /* > 0: per-label stats capacity per frame */
+    int32_t tap_rule;     /* VA_TAPS_CV4 (0, default) | VA_TAPS_CV3: the 8-bit Gaussian's tap set */
 } va_config;
 
 typedef struct va_pipeline va_pipeline_t;
 
 int va_pipeline_create(const va_config *cfg, va_pipeline_t **out);
 int va_pipeline_destroy(va_pipeline_t *p);
-/* frames_dev: (n,H,W[,C]) of cfg.dtype.  Any output may be NULL:
+/* frames_dev: (n,H,W[,C]) of cfg.dtype (float32 pipelines: 16-byte aligned, as is filtered_out_dev;
+ * VA_ERR_INVALID otherwise).  Any output may be NULL:
  *   filtered_out_dev : (n,H,W[,C]) cfg.dtype, the blurred background-subtracted frames
  *   mask_out_dev     : (n,H,W) u8 0/maxval after threshold + morphology
  *   labels_out_dev   : (n,H,W) int32

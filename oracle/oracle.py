@@ -37,6 +37,8 @@ def lib():
         _lib.vao_gauss_taps_q8.argtypes = [C.c_double, C.POINTER(C.c_int), C.c_void_p]
         _lib.vao_gauss_taps_f32.argtypes = [C.c_double, C.POINTER(C.c_int), C.c_void_p]
         _lib.vao_gaussian_u8.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_double]
+        _lib.vao_gauss_taps_q8_rule.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_int), C.c_void_p]
+        _lib.vao_gaussian_u8_rule.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_double, C.c_int]
         _lib.vao_gaussian_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_double]
         _lib.vao_bg_mean_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                         C.c_size_t]
@@ -95,11 +97,16 @@ def gauss_ksize(sigma, is_u8=True):
     return lib().vao_gauss_ksize(float(sigma), int(bool(is_u8)))
 
 
-def gauss_taps_q8(sigma):
-    """OpenCV 8-bit fixed-point taps (unsigned 8.8, sum == 256)"""
+TAP_RULES = {"cv4": 0, "cv3": 1}
+
+
+def gauss_taps_q8(sigma, tap_rule="cv4"):
+    """OpenCV 8-bit fixed-point taps: 'cv4' = unsigned 8.8 with error diffusion (sum == 256, OpenCV
+    >= 4.x), 'cv3' = cvRound(k_i * 256) tap by tap on the float32 kernel (OpenCV 2.4 / 3.x, the
+    reference's era; the sum is not forced)"""
     buf = np.zeros(1024, np.uint16)
     ks = C.c_int()
-    if lib().vao_gauss_taps_q8(float(sigma), C.byref(ks), _p(buf)):
+    if lib().vao_gauss_taps_q8_rule(float(sigma), TAP_RULES[tap_rule], C.byref(ks), _p(buf)):
         raise ValueError("bad sigma %r" % (sigma,))
     return buf[:ks.value].copy()
 
@@ -127,11 +134,11 @@ def _nhwc(a, frame_ndim_hint=None):
     raise ValueError("unsupported shape %r" % (a.shape,))
 
 
-def gaussian_u8(frames, sigma, layout=None):
+def gaussian_u8(frames, sigma, layout=None, tap_rule="cv4"):
     """FilterBlur._process_frame (video/filters.py:388-392) on u8 frames"""
     a, n, h, w, c = _nhwc(np.asarray(frames, np.uint8), layout)
     out = np.empty_like(a)
-    if lib().vao_gaussian_u8(_p(a), _p(out), n, h, w, c, float(sigma)):
+    if lib().vao_gaussian_u8_rule(_p(a), _p(out), n, h, w, c, float(sigma), TAP_RULES[tap_rule]):
         raise ValueError("gaussian_u8 failed")
     return out
 

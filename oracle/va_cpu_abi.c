@@ -19,6 +19,8 @@
 
 /* oracle entry points (va_oracle.c, linked into the same library) */
 int vao_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps);
+int vao_gauss_taps_q8_rule(double sigma, int rule, int *ksize_out, uint16_t *taps);
+int vao_gaussian_u8_rule(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma, int rule);
 int vao_gauss_taps_f32(double sigma, int *ksize_out, float *taps);
 int vao_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma);
 int vao_gaussian_f32(const float *src, float *dst, int n, int h, int w, int c, double sigma);
@@ -61,6 +63,24 @@ int va_gauss_taps_q8(double sigma, int *ks, uint16_t *taps, int cap)
     if (k > cap) FAIL(VA_ERR_RANGE, "va_gauss_taps_q8: %d taps > capacity %d", k, cap);
     memcpy(taps, t, sizeof(uint16_t) * (size_t)k);
     *ks = k;
+    return VA_OK;
+}
+int va_gauss_taps_q8_rule(double sigma, int rule, int *ks, uint16_t *taps, int cap)
+{
+    uint16_t t[512];
+    int k;
+    if (!ks || !taps || vao_gauss_taps_q8_rule(sigma, rule, &k, t)) FAIL(VA_ERR_INVALID, "va_gauss_taps_q8_rule: bad argument");
+    if (k > cap) FAIL(VA_ERR_RANGE, "va_gauss_taps_q8_rule: %d taps > capacity %d", k, cap);
+    memcpy(taps, t, sizeof(uint16_t) * (size_t)k);
+    *ks = k;
+    return VA_OK;
+}
+int va_gaussian_u8_rule(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma, int rule, void *st)
+{
+    (void)st;
+    if (!src || !dst || src == dst) FAIL(VA_ERR_INVALID, "va_gaussian_u8_rule: src/dst must be distinct non-NULL");
+    if (n < 0 || h <= 0 || w <= 0 || c <= 0) FAIL(VA_ERR_INVALID, "va_gaussian_u8_rule: bad shape");
+    if (vao_gaussian_u8_rule(src, dst, n, h, w, c, sigma, rule)) FAIL(VA_ERR_INVALID, "va_gaussian_u8_rule: bad sigma / rule");
     return VA_OK;
 }
 int va_gauss_taps_f32(double sigma, int *ks, float *taps, int cap)

@@ -88,9 +88,46 @@ static int gauss_taps_f64(double sigma, int n, double *out)
     return 0;
 }
 
-int vao_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps)
+/* The reference-era definition (rule 1, "cv3").  The reference calls cv2.findContours(...)[1]
+ * (video/analysis/regions.py:180-182), i.e. OpenCV 2.4 / 3.x, whose 8-bit GaussianBlur
+ * (video/filters.py:392) ran sepFilter2D on float32 kernels scaled to integers:
+ *   getGaussianKernel(n, sigma, CV_32F): t_i = (float)exp(-x_i^2 / (2 sigma^2)), sum over the float
+ *   values in double, k_i = (float)(t_i * (1 / sum));
+ *   createSeparableLinearFilter (8-bit source and destination, smooth symmetric kernels):
+ *   kernel.convertTo(CV_32S, 256) -> tap_i = cvRound(k_i * 256), every tap on its own (no error
+ *   diffusion, the sum is whatever it comes to: 253..259 for sigma = 5), int32 row sums,
+ *   column pass (acc + 2^15) >> 16 saturated to 8 bits (FixedPtCastEx<int, uchar>, bits = 16).
+ * Written from upstream knowledge like rule 0; unverifiable offline (no cv2 of either era). */
+static int gauss_taps_q8_cv3(double sigma, int n, uint16_t *taps)
+{
+    if (n < 1 || n > VAO_MAX_TAPS || !(sigma > 0))
+        return -1;
+    float cf[VAO_MAX_TAPS];
+    double scale2x = -0.5 / (sigma * sigma), sum = 0.0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        cf[i] = (float)exp(scale2x * x * x);
+        sum += cf[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; i++) {
+        float k = (float)(cf[i] * sum);
+        taps[i] = (uint16_t)cv_round((double)(k * 256.0f));      /* (x 2^8 is exact in float) */
+    }
+    return 0;
+}
+
+int vao_gauss_taps_q8_rule(double sigma, int rule, int *ksize_out, uint16_t *taps)
 {
     int n = vao_gauss_ksize(sigma, 1);
+    if (rule == 1) {
+        if (gauss_taps_q8_cv3(sigma, n, taps))
+            return -1;
+        *ksize_out = n;
+        return 0;
+    }
+    if (rule != 0)
+        return -1;
     double k[VAO_MAX_TAPS];
     if (gauss_taps_f64(sigma, n, k))
         return -1;
@@ -111,6 +148,11 @@ int vao_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps)
     return 0;
 }
 
+int vao_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps)
+{
+    return vao_gauss_taps_q8_rule(sigma, 0, ksize_out, taps);
+}
+
 int vao_gauss_taps_f32(double sigma, int *ksize_out, float *taps)
 {
     int n = vao_gauss_ksize(sigma, 0);
@@ -123,17 +165,18 @@ int vao_gauss_taps_f32(double sigma, int *ksize_out, float *taps)
     return 0;
 }
 
-/* frames: (n, h, w, c) u8 contiguous; each channel independently */
-int vao_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
-                    double sigma)
+/* frames: (n, h, w, c) u8 contiguous; each channel independently.  rule: 0 = OpenCV >= 4.x taps
+ * (sum 256: row sums fit 16 bits), 1 = the 2.4 / 3.x taps (any sum: int32 row sums, as there) */
+int vao_gaussian_u8_rule(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
+                         double sigma, int rule)
 {
     uint16_t taps[VAO_MAX_TAPS];
     int ks;
-    if (vao_gauss_taps_q8(sigma, &ks, taps))
+    if (vao_gauss_taps_q8_rule(sigma, rule, &ks, taps))
         return -1;
     int r = ks / 2;
     size_t fsz = (size_t)h * w * c;
-    uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * fsz);
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * fsz);
     int *xi = (int *)malloc(sizeof(int) * (size_t)(w + 2 * r));
     int *yi = (int *)malloc(sizeof(int) * (size_t)(h + 2 * r));
     for (int x = -r; x < w + r; x++)
@@ -149,7 +192,7 @@ int vao_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c
                     uint32_t acc = 0;
                     for (int i = 0; i < ks; i++)
                         acc += (uint32_t)taps[i] * s[((size_t)y * w + xi[x + i]) * c + ch];
-                    tmp[((size_t)y * w + x) * c + ch] = (uint16_t)acc; /* <= 255*256 */
+                    tmp[((size_t)y * w + x) * c + ch] = acc;
                 }
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++)
@@ -165,6 +208,11 @@ int vao_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c
     free(xi);
     free(yi);
     return 0;
+}
+
+int vao_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma)
+{
+    return vao_gaussian_u8_rule(src, dst, n, h, w, c, sigma, 0);
 }
 
 /* Float path: cv2.GaussianBlur on a non-8-bit image, as at

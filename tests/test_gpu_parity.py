@@ -37,6 +37,38 @@ def _blob_clip(n, h, w, seed, nblobs=6, salt=0.0):
 
 
 # ---------------------------------------------------------------------------- Gaussian
+@pytest.mark.parametrize("sigma", [0.5, 1.0, 1.7, 2.0, 2.4, 3.0, 4.0, 5.0, 7.0])
+def test_gaussian_u8_reference_era_taps(ops, oracle, sigma):
+    """tap_rule='cv3' (OpenCV 2.4 / 3.x: every float32 tap rounded on its own, sum 251..259): the
+    matrix-core kernel where the tap set allows it (sum <= 256, taps <= 127), the generic path with
+    16- or 32-bit row sums otherwise, saturation for sums above 256 -- against the oracle"""
+    from video import _hip
+    assert np.array_equal(_hip.gauss_taps_q8(sigma, "cv3"), oracle.gauss_taps_q8(sigma, "cv3"))
+    rng = np.random.default_rng(int(sigma * 13))
+    for shape, color in (((3, 97, 208), False), ((2, 64, 75), False), ((1, 40, 64, 3), True)):
+        im = rng.integers(0, 256, shape, dtype=np.uint8)
+        im[0, :12] = 255                                   # saturating regions: sums above 256 overshoot 255
+        ref = oracle.gaussian_u8(im, sigma, tap_rule="cv3")
+        assert np.array_equal(ops.gaussian_blur(im, sigma, color=color, tap_rule="cv3"), ref), (sigma, shape)
+
+
+def test_pipeline_with_reference_era_taps(oracle):
+    from video.engine import FrameEngine
+    clip = _blob_clip(6, 96, 160, seed=21, salt=0.002)
+    for sigma in (2.0, 5.0):                               # 257 (generic path), 256 (matrix cores)
+        eng = FrameEngine(size=(160, 96), max_batch=6, background="mean", sigma=sigma, thresh=20, tap_rule="cv3",
+                          morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4)
+        out = eng.run(clip, want=("filtered", "mask", "labels", "counts"))
+        eng.close()
+        diff, _ = oracle.bg_mean_u8(clip)
+        blur = oracle.gaussian_u8(diff, sigma, tap_rule="cv3")
+        m = oracle.threshold_u8(blur, 20)
+        m = oracle.morph_u8(oracle.morph_u8(m, oracle.DILATE, oracle.RECT, 5), oracle.ERODE, oracle.RECT, 5)
+        rl, rc = oracle.label_batch(m, 4)
+        assert np.array_equal(out["filtered"], blur) and np.array_equal(out["mask"], m)
+        assert np.array_equal(out["labels"], rl) and np.array_equal(out["counts"], rc)
+
+
 @pytest.mark.parametrize("impl", [None, "generic"])
 def test_gaussian_u8_golden(ops, golden, impl):
     for nm in ("imp", "step", "ramp", "noise", "tiny"):

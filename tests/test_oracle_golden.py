@@ -313,3 +313,42 @@ def test_contour_moments_known_answers(oracle):
     assert abs(cm["m00"] - oracle.contour_area(np.asarray(c, np.int32))) < 1e-9
     assert abs(cm["m10"] / cm["m00"] - 45) < 1e-9 and abs(cm["m01"] / cm["m00"] - 38) < 1e-9
     assert abs(cm["mu20"] - cm["mu02"]) / cm["mu20"] < 1e-9 and abs(cm["mu11"]) < 1e-6
+
+
+# ---------------------------------------------------------------------------- reference-era Gaussian taps
+def _cv3_taps_numpy(sigma):
+    """OpenCV 2.4 / 3.x: float32 getGaussianKernel, every tap cvRound(k * 256) on its own -- restated
+    here with NumPy float32 arithmetic, independently of the C oracle"""
+    n = int(np.rint(sigma * 6 + 1)) | 1
+    x = np.arange(n) - (n - 1) * 0.5
+    cf = np.exp(-0.5 / (sigma * sigma) * x * x).astype(np.float32)
+    inv = 1.0 / cf.astype(np.float64).sum()
+    k = (cf.astype(np.float64) * inv).astype(np.float32)
+    return np.rint(k.astype(np.float64) * 256.0).astype(np.uint16)          # rint: ties to even, as cvRound
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.0, 1.7, 2.0, 2.4, 3.0, 5.0, 7.0])
+def test_cv3_taps_and_blur(oracle, sigma):
+    taps = oracle.gauss_taps_q8(sigma, "cv3")
+    assert np.array_equal(taps, _cv3_taps_numpy(sigma))
+    assert np.array_equal(taps, taps[::-1])
+    s = int(taps.sum())
+    assert abs(s - 256) <= len(taps) // 2           # not forced to 256 ...
+    if sigma in (1.7, 2.0, 2.4, 7.0):
+        assert s != 256                             # ... and it is not (258, 257, 259, 251)
+    # a constant image c comes out as sat((c * S^2 + 2^15) >> 16): gain != 1 is part of the definition
+    for c in (0, 1, 100, 254, 255):
+        out = oracle.gaussian_u8(np.full((1, 40, 48), c, np.uint8), sigma, tap_rule="cv3")
+        assert np.all(out == min(255, (c * s * s + 32768) >> 16)), (sigma, c)
+    # the default rule keeps unity gain
+    assert int(oracle.gauss_taps_q8(sigma).sum()) == 256
+    # literal two-pass integer convolution with the NumPy taps (reflect-101 borders)
+    rng = np.random.default_rng(int(sigma * 10))
+    im = rng.integers(0, 256, (23, 37), dtype=np.uint8)
+    r = len(taps) // 2
+    pad = np.pad(im.astype(np.int64), ((0, 0), (r, r)), mode="reflect")
+    rows = sum(int(taps[i]) * pad[:, i:i + im.shape[1]] for i in range(len(taps)))
+    pad = np.pad(rows, ((r, r), (0, 0)), mode="reflect")
+    acc = sum(int(taps[j]) * pad[j:j + im.shape[0], :] for j in range(len(taps)))
+    ref = np.minimum((acc + 32768) >> 16, 255).astype(np.uint8)
+    assert np.array_equal(oracle.gaussian_u8(im, sigma, tap_rule="cv3"), ref)

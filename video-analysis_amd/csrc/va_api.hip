@@ -157,6 +157,17 @@ int va_init(int device)
     return VA_OK;
 }
 
+int va_trim(size_t keep_bytes)
+{
+    VA_ENTER();
+    VA_REQUIRE(g_device >= 0, "va_trim: va_init has not run");
+    hipMemPool_t pool;
+    VA_HIP(hipDeviceGetDefaultMemPool(&pool, g_device));
+    VA_HIP(hipDeviceSynchronize());
+    VA_HIP(hipMemPoolTrimTo(pool, keep_bytes));
+    return VA_OK;
+}
+
 int va_malloc(void **dev_ptr, size_t bytes)
 {
     VA_ENTER();
@@ -290,9 +301,13 @@ int va_event_elapsed_ms(void *start_event, void *stop_event, float *ms_out)
 // ------------------------------------------------------------------------------ Gaussian
 int va_gauss_taps_q8(double sigma, int *ksize_out, uint16_t *taps_out, int capacity)
 {
+    return va_gauss_taps_q8_rule(sigma, VA_TAPS_CV4, ksize_out, taps_out, capacity);
+}
+int va_gauss_taps_q8_rule(double sigma, int tap_rule, int *ksize_out, uint16_t *taps_out, int capacity)
+{
     VA_REQUIRE(ksize_out && taps_out, "va_gauss_taps_q8: NULL argument");
     TapsQ8 t;
-    int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
+    int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps, tap_rule);
     if (rc)
         return rc;
     if (t.ksize > capacity) {
@@ -350,6 +365,12 @@ static int blur_u8_planes(const uint8_t *src, uint8_t *dst, int n, int h, int w,
 int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma,
                    void *stream)
 {
+    return va_gaussian_u8_rule(src, dst, n, h, w, c, sigma, VA_TAPS_CV4, stream);
+}
+
+int va_gaussian_u8_rule(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c, double sigma,
+                        int tap_rule, void *stream)
+{
     VA_ENTER();
     VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
                "va_gaussian_u8: frames above 2^29 pixels are not supported");
@@ -357,7 +378,7 @@ int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
     VA_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "va_gaussian_u8: bad shape (%d,%d,%d,%d)", n, h,
                w, c);
     TapsQ8 t;
-    int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps);
+    int rc = gauss_taps_q8(sigma, &t.ksize, t.t, kMaxTaps, tap_rule);
     if (rc)
         return rc;
     if (c == 1 && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
@@ -374,10 +395,10 @@ int va_gaussian_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int c,
             return rc;
         return blur_u8_planes(src, dst, n, h, w, wp, c, t, scratch.ptr, as_stream(stream));
     }
-    rc = scratch.acquire((size_t)n * h * w * c * sizeof(uint16_t), as_stream(stream));
+    rc = scratch.acquire(gauss_generic_u8_scratch_bytes((size_t)n * h * w * c, t), as_stream(stream));
     if (rc)
         return rc;
-    return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch.ptr, n, h, w, c, t, as_stream(stream));
+    return launch_gauss_generic_u8(src, dst, scratch.ptr, n, h, w, c, t, as_stream(stream));
 }
 
 // test hook: force the generic two-pass implementation
@@ -394,10 +415,10 @@ int va_gaussian_u8_generic(const uint8_t *src, uint8_t *dst, int n, int h, int w
     if (rc)
         return rc;
     ScratchLease scratch;
-    rc = scratch.acquire((size_t)n * h * w * c * sizeof(uint16_t), as_stream(stream));
+    rc = scratch.acquire(gauss_generic_u8_scratch_bytes((size_t)n * h * w * c, t), as_stream(stream));
     if (rc)
         return rc;
-    return launch_gauss_generic_u8(src, dst, (uint16_t *)scratch.ptr, n, h, w, c, t, as_stream(stream));
+    return launch_gauss_generic_u8(src, dst, scratch.ptr, n, h, w, c, t, as_stream(stream));
 }
 
 // test hook: force the LDS/VALU (dot4/dot2) fused implementation
@@ -845,6 +866,8 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
                "va_pipeline_create: morph_count %d out of range", cfg->morph_count);
     VA_REQUIRE(cfg->connectivity == 0 || cfg->connectivity == 4 || cfg->connectivity == 8,
                "va_pipeline_create: connectivity must be 0, 4 or 8");
+    VA_REQUIRE(cfg->tap_rule == VA_TAPS_CV4 || cfg->tap_rule == VA_TAPS_CV3,
+               "va_pipeline_create: tap_rule must be VA_TAPS_CV4 or VA_TAPS_CV3");
     const bool masks = cfg->thresh >= 0;
     if (cfg->dtype == VA_F32) {
         VA_REQUIRE(!masks, "va_pipeline_create: threshold/labelling need uint8 frames");
@@ -896,7 +919,7 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
 
     if (cfg->sigma > 0) {
         if (cfg->dtype == VA_U8) {
-            PIPE_TRY(gauss_taps_q8(cfg->sigma, &p->tq.ksize, p->tq.t, kMaxTaps));
+            PIPE_TRY(gauss_taps_q8(cfg->sigma, &p->tq.ksize, p->tq.t, kMaxTaps, cfg->tap_rule));
             p->mfma = cfg->channels == 1 && !g_gauss_u8_valu && gauss_mfma_supported(cfg->width, cfg->height, p->tq);
             p->fused = p->mfma ||
                        (cfg->channels == 1 && gauss_fused_supported(cfg->width, cfg->height, p->tq));
@@ -931,7 +954,7 @@ int va_pipeline_create(const va_config *cfg, va_pipeline_t **out)
             PIPE_MALLOC(p->bg_recip, bg_scratch_bytes(cfg->max_batch));
     }
     if (cfg->sigma > 0 && !p->fused) {
-        size_t gs = nb * p->px * (cfg->dtype == VA_U8 ? 2 : 4);
+        size_t gs = cfg->dtype == VA_U8 ? gauss_generic_u8_scratch_bytes(nb * p->px, p->tq) : nb * p->px * 4;
         if (cfg->dtype == VA_U8) {
             p->planes_wp = planes_width(cfg->height, cfg->width, cfg->channels, p->tq);
             if (p->planes_wp)
@@ -1130,7 +1153,12 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     VA_MARK(nullptr);
 
     // float32 frames: background update, difference and row pass in one kernel, then the columns
+    // (16-byte aligned frame pointers: a contract of float32 pipelines, see the header)
     if (c.dtype == VA_F32 && p->f32_fused) {
+        VA_REQUIRE(reinterpret_cast<uintptr_t>(frames) % 16 == 0 &&
+                       (!filtered_out || reinterpret_cast<uintptr_t>(filtered_out) % 16 == 0),
+                   "va_pipeline_run: float32 pipelines need 16-byte aligned frames_dev / filtered_out_dev "
+                   "(hipMalloc'ed buffers and whole-frame offsets into them are)");
         void *dst = filtered_out ? filtered_out : p->blur;
         const bool ema = c.bg_mode == VA_BG_EMA;
         rc = launch_gauss_f32_fused((const float *)frames, (float *)dst, (float *)p->gscratch,
@@ -1198,7 +1226,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
                                     p->planes_wp, c.channels, p->tq, p->gscratch, st);
             else if (c.dtype == VA_U8)
                 rc = launch_gauss_generic_u8((const uint8_t *)cur, (uint8_t *)dst,
-                                             (uint16_t *)p->gscratch, n, c.height, c.width,
+                                             p->gscratch, n, c.height, c.width,
                                              c.channels, p->tq, st);
             else if (gauss_f32_fast_supported(c.width, c.channels, p->tf))
                 rc = launch_gauss_f32_fast((const float *)cur, (float *)dst, (float *)p->gscratch, n,

@@ -81,7 +81,7 @@ inline int words_per_row(int w) { return (w + 31) / 32; }
 // ---- host-side kernels shared between translation units --------------------------------
 // Gaussian taps (host): OpenCV's 8-bit fixed-point / float definitions. Return 0 or VA_ERR_*.
 int gauss_ksize(double sigma, bool is_u8);
-int gauss_taps_q8(double sigma, int *ksize, uint16_t *taps, int cap);
+int gauss_taps_q8(double sigma, int *ksize, uint16_t *taps, int cap, int rule = VA_TAPS_CV4);
 int gauss_taps_f32(double sigma, int *ksize, float *taps, int cap);
 
 // ---- launchers (each enqueues on `stream`, returns VA_OK or an error) -------------------
@@ -96,7 +96,9 @@ struct TapsF32 {
 };
 
 // generic (any radius / channel count) two-pass Gaussian through a u16 / f32 scratch in HBM
-int launch_gauss_generic_u8(const uint8_t *src, uint8_t *dst, uint16_t *scratch, int n, int h,
+// scratch: gauss_generic_u8_scratch_bytes(n*h*w*c, taps) bytes (16-bit row sums while the tap sum allows)
+size_t gauss_generic_u8_scratch_bytes(size_t count, const TapsQ8 &taps);
+int launch_gauss_generic_u8(const uint8_t *src, uint8_t *dst, void *scratch, int n, int h,
                             int w, int c, const TapsQ8 &taps, hipStream_t st);
 int launch_gauss_generic_f32(const float *src, float *dst, float *scratch, int n, int h, int w,
                              int c, const TapsF32 &taps, hipStream_t st);

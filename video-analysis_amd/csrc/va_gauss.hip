@@ -45,13 +45,34 @@ static int taps_f64(double sigma, int n, double *out)
     return 0;
 }
 
-int gauss_taps_q8(double sigma, int *ksize, uint16_t *taps, int cap)
+int gauss_taps_q8(double sigma, int *ksize, uint16_t *taps, int cap, int rule)
 {
     VA_REQUIRE(sigma > 0 && sigma == sigma, "gaussian: sigma must be > 0 (got %g)", sigma);
+    VA_REQUIRE(rule == VA_TAPS_CV4 || rule == VA_TAPS_CV3, "gaussian: unknown tap rule %d", rule);
     const int n = gauss_ksize(sigma, true);
     if (n > cap) {
         set_error("gaussian: sigma=%g needs %d taps, more than the supported %d", sigma, n, cap);
         return VA_ERR_RANGE;
+    }
+    *ksize = n;
+    if (rule == VA_TAPS_CV3) {
+        // OpenCV 2.4 / 3.x (the reference's era, video/analysis/regions.py:180-182): float32
+        // getGaussianKernel -- exp values rounded to float, summed in double, scaled, rounded to float --
+        // then every tap cvRound(k * 256) on its own; the sum is not forced to 256
+        float cf[kMaxTaps + 1];
+        const double scale2x = -0.5 / (sigma * sigma);
+        double sum = 0.0;
+        for (int i = 0; i < n; i++) {
+            const double x = i - (n - 1) * 0.5;
+            cf[i] = (float)exp(scale2x * x * x);
+            sum += cf[i];
+        }
+        sum = 1.0 / sum;
+        for (int i = 0; i < n; i++) {
+            const float k = (float)(cf[i] * sum);
+            taps[i] = (uint16_t)cv_round((double)(k * 256.0f));
+        }
+        return VA_OK;
     }
     double k[kMaxTaps + 1];
     taps_f64(sigma, n, k);
@@ -68,7 +89,6 @@ int gauss_taps_q8(double sigma, int *ksize, uint16_t *taps, int cap)
         sum += v0;
     }
     taps[n2] = (uint16_t)(256 - 2 * sum);
-    *ksize = n;
     return VA_OK;
 }
 
@@ -103,8 +123,10 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// T = uint16_t while the row sums fit (tap sum <= 257: every OpenCV >= 4 tap set), uint32_t otherwise
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-gauss_row_u8_generic(const uint8_t *__restrict__ src, uint16_t *__restrict__ tmp, int w, int c,
+gauss_row_u8_generic(const uint8_t *__restrict__ src, T *__restrict__ tmp, int w, int c,
                      TapsQ8 taps, size_t total)
 {
     size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -119,11 +141,12 @@ gauss_row_u8_generic(const uint8_t *__restrict__ src, uint16_t *__restrict__ tmp
     uint32_t acc = 0;
     for (int i = 0; i < taps.ksize; i++)
         acc += (uint32_t)taps.t[i] * row[(size_t)reflect101(x + i - r, w) * c + ch];
-    tmp[e] = (uint16_t)acc;  // <= 255*256
+    tmp[e] = (T)acc;
 }
 
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-gauss_col_u8_generic(const uint16_t *__restrict__ tmp, uint8_t *__restrict__ dst, int h, int w,
+gauss_col_u8_generic(const T *__restrict__ tmp, uint8_t *__restrict__ dst, int h, int w,
                      int c, TapsQ8 taps, size_t total)
 {
     size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -133,7 +156,7 @@ gauss_col_u8_generic(const uint16_t *__restrict__ tmp, uint8_t *__restrict__ dst
     size_t col = e % wc;
     size_t rowi = e / wc;
     int y = (int)(rowi % h);
-    const uint16_t *frame = tmp + (rowi - y) * wc;
+    const T *frame = tmp + (rowi - y) * wc;
     const int r = taps.ksize >> 1;
     uint32_t acc = 0;
     for (int j = 0; j < taps.ksize; j++)
@@ -186,16 +209,35 @@ gauss_col_f32_generic(const float *__restrict__ tmp, float *__restrict__ dst, in
 
 }  // namespace
 
-int launch_gauss_generic_u8(const uint8_t *src, uint8_t *dst, uint16_t *scratch, int n, int h,
+static int taps_sum(const TapsQ8 &taps)
+{
+    int sum = 0;
+    for (int i = 0; i < taps.ksize; i++)
+        sum += taps.t[i];
+    return sum;
+}
+
+size_t gauss_generic_u8_scratch_bytes(size_t count, const TapsQ8 &taps)
+{
+    return count * (taps_sum(taps) <= 257 ? sizeof(uint16_t) : sizeof(uint32_t));     // row sums <= 255 * sum
+}
+
+int launch_gauss_generic_u8(const uint8_t *src, uint8_t *dst, void *scratch, int n, int h,
                             int w, int c, const TapsQ8 &taps, hipStream_t st)
 {
     size_t total = (size_t)n * h * w * c;
     if (total == 0)
         return VA_OK;
     int grid = cdiv((long long)total, kBlock);
-    gauss_row_u8_generic<<<grid, kBlock, 0, st>>>(src, scratch, w, c, taps, total);
-    VA_LAUNCH_CHECK("gauss_row_u8_generic");
-    gauss_col_u8_generic<<<grid, kBlock, 0, st>>>(scratch, dst, h, w, c, taps, total);
+    if (taps_sum(taps) <= 257) {
+        gauss_row_u8_generic<uint16_t><<<grid, kBlock, 0, st>>>(src, (uint16_t *)scratch, w, c, taps, total);
+        VA_LAUNCH_CHECK("gauss_row_u8_generic");
+        gauss_col_u8_generic<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t *)scratch, dst, h, w, c, taps, total);
+    } else {
+        gauss_row_u8_generic<uint32_t><<<grid, kBlock, 0, st>>>(src, (uint32_t *)scratch, w, c, taps, total);
+        VA_LAUNCH_CHECK("gauss_row_u8_generic");
+        gauss_col_u8_generic<uint32_t><<<grid, kBlock, 0, st>>>((const uint32_t *)scratch, dst, h, w, c, taps, total);
+    }
     VA_LAUNCH_CHECK("gauss_col_u8_generic");
     return VA_OK;
 }

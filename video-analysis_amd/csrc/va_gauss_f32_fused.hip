@@ -1376,6 +1376,8 @@ bool gauss_f32_fused_supported(int h, int w, int c, const TapsF32 &taps)
     const int r = taps.ksize / 2;
     if (r > 60)          // the marching column tile must fit 64 KB of LDS four times per CU
         return false;
+    if ((long long)h * w * c >= (1ll << 30))    // byte offsets inside a frame travel as 32-bit values (4 * h*w*c)
+        return false;
     return plan_rows(h, w, c, taps, 1024, &p);
 }
 

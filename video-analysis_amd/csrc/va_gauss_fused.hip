@@ -338,10 +338,13 @@ bool gauss_fused_supported(int w, int h, const TapsQ8 &taps)
         return false;
     if (taps.ksize < 3 || taps.ksize / 2 > 16)
         return false;
-    for (int i = 0; i < taps.ksize; i++)
+    int sum = 0;
+    for (int i = 0; i < taps.ksize; i++) {
         if (taps.t[i] > 255)
             return false;
-    return true;
+        sum += taps.t[i];
+    }
+    return sum <= 256;          // 16-bit row sums, and (acc + 2^15) >> 16 <= 255 without saturation
 }
 
 int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n,

@@ -16,6 +16,8 @@ VA_U8, VA_F32, VA_F64 = 0, 1, 2
 BG_NONE, BG_MEAN, BG_EMA, BG_STATIC = 0, 1, 2, 3
 MORPH_ERODE, MORPH_DILATE = 0, 1
 SHAPE_RECT, SHAPE_CROSS, SHAPE_ELLIPSE = 0, 1, 2
+TAPS_CV4, TAPS_CV3 = 0, 1
+TAP_RULES = {None: TAPS_CV4, "cv4": TAPS_CV4, "cv3": TAPS_CV3}
 MAX_MORPH_OPS = 4
 STATS_STRIDE = 16
 STAT_NAMES = ("area", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03",
@@ -49,7 +51,7 @@ class va_config(C.Structure):
                 ("morph_op", C.c_int32 * MAX_MORPH_OPS),
                 ("morph_shape", C.c_int32 * MAX_MORPH_OPS),
                 ("morph_ksize", C.c_int32 * MAX_MORPH_OPS),
-                ("connectivity", C.c_int32), ("max_labels", C.c_int32)]
+                ("connectivity", C.c_int32), ("max_labels", C.c_int32), ("tap_rule", C.c_int32)]
 
 
 _vp, _i, _sz, _d, _i64 = C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_int64
@@ -60,6 +62,7 @@ SIGNATURES = {
     "va_device_count": (_i, []),
     "va_version": (C.c_char_p, []),
     "va_last_error": (C.c_char_p, []),
+    "va_trim": (_i, [_sz]),
     "va_malloc": (_i, [C.POINTER(_vp), _sz]),
     "va_free": (_i, [_vp]),
     "va_host_alloc": (_i, [C.POINTER(_vp), _sz]),
@@ -79,7 +82,9 @@ SIGNATURES = {
     "va_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "va_gaussian_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "va_gaussian_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
+    "va_gaussian_u8_rule": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _i, _vp]),
     "va_gauss_taps_q8": (_i, [_d, C.POINTER(_i), _vp, _i]),
+    "va_gauss_taps_q8_rule": (_i, [_d, _i, C.POINTER(_i), _vp, _i]),
     "va_gauss_taps_f32": (_i, [_d, C.POINTER(_i), _vp, _i]),
     "va_bg_update": (_i, [_i, _i, _vp, _vp, _vp, _i64, _d, _i, _sz, _vp]),
     "va_welford_u8": (_i, [_vp, _vp, _vp, _i64, _i, _sz, _vp]),
@@ -239,11 +244,12 @@ class DeviceBuffer(object):
             pass
 
 
-def gauss_taps_q8(sigma):
-    """the unsigned 8.8 fixed-point taps used by FilterBlur on uint8 frames (host only)"""
+def gauss_taps_q8(sigma, tap_rule="cv4"):
+    """the unsigned 8.8 fixed-point taps used by FilterBlur on uint8 frames (host only); tap_rule
+    'cv4' (OpenCV >= 4: error diffusion, sum 256) or 'cv3' (OpenCV 2.4 / 3.x: tap-by-tap rounding)"""
     buf = np.zeros(256, np.uint16)
     ks = C.c_int()
-    check(load_library().va_gauss_taps_q8(float(sigma), C.byref(ks), buf.ctypes.data, 256))
+    check(load_library().va_gauss_taps_q8_rule(float(sigma), TAP_RULES[tap_rule], C.byref(ks), buf.ctypes.data, 256))
     return buf[:ks.value].copy()
 
 

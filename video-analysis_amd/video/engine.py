@@ -18,7 +18,7 @@ class FrameEngine(object):
 
     def __init__(self, size, channels=1, dtype=np.uint8, max_batch=64, background=None,
                  bg_rate=0.02, sigma=0.0, thresh=None, maxval=255, morphology=(),
-                 connectivity=0, max_labels=0, device=None, prepare=None):
+                 connectivity=0, max_labels=0, device=None, prepare=None, tap_rule="cv4"):
         """size = (width, height) as everywhere in the reference (video/io/base.py:40-55).
         background: None | 'mean' | 'ema' | 'static';  morphology: sequence of
         (op, shape, ksize) with op in {'erode','dilate'}, shape in {'rect','cross','ellipse'}.
@@ -57,6 +57,7 @@ class FrameEngine(object):
             cfg.morph_ksize[i] = int(ksize)
         cfg.connectivity = self.connectivity
         cfg.max_labels = self.max_labels
+        cfg.tap_rule = _hip.TAP_RULES[tap_rule]        # 8-bit Gaussian taps: 'cv4' | 'cv3' (reference-era OpenCV)
         self._cfg = cfg
         self._lib = _hip.lib(device)
         self._handle = C.c_void_p()

@@ -268,7 +268,7 @@ class _GpuStage(object):
             return None
         if "morphology" in kinds and "threshold" not in kinds:
             return None                     # the engine's morphology works on thresholded masks
-        args = dict(background=None, rate=0.02, sigma=0.0, threshold=None, morphology=(),
+        args = dict(background=None, rate=0.02, sigma=0.0, threshold=None, morphology=(), tap_rule="cv4",
                     connectivity=0, static_background=None, prepare=prepare, size=stages[0]._source.size)
         maxval = 255
         steps = []
@@ -277,7 +277,7 @@ class _GpuStage(object):
             if kind == "background":
                 args.update(background=par["mode"], rate=par["rate"], static_background=par["background"])
             elif kind == "blur":
-                args["sigma"] = par["sigma"]
+                args["sigma"], args["tap_rule"] = par["sigma"], par["tap_rule"]
             elif kind == "threshold":
                 args["threshold"], maxval = par["threshold"], par["maxval"]
             else:
@@ -392,16 +392,22 @@ class FilterBlur(_GpuStage, VideoFilterBase):
     cv2.GaussianBlur(frame.astype(np.uint8), (0, 0), sigma)).  Unlike the reference
      listeners ARE notified."""
 
-    def __init__(self, source, sigma=3):
+    def __init__(self, source, sigma=3, tap_rule="cv4"):
+        """tap_rule: which OpenCV's 8-bit Gaussian -- 'cv4' (>= 4.x: fixed-point taps with error
+        diffusion, sum 256) or 'cv3' (2.4 / 3.x, the reference's era: every float32 tap rounded on its
+        own).  Both are written definitions, unverifiable offline."""
         self.sigma = sigma
+        if tap_rule not in ("cv4", "cv3"):
+            raise ValueError("tap_rule must be 'cv4' or 'cv3'")
+        self.tap_rule = tap_rule
         super(FilterBlur, self).__init__(source)
 
     def _stage(self):
-        return "blur", {"sigma": float(self.sigma)}
+        return "blur", {"sigma": float(self.sigma), "tap_rule": self.tap_rule}
 
     def _process_frame(self, frame):
         frame = np.asarray(frame).astype(np.uint8)          # C truncation/wrap like the reference
-        out = ops.gaussian_blur(frame, self.sigma, color=frame.ndim == 3)
+        out = ops.gaussian_blur(frame, self.sigma, color=frame.ndim == 3, tap_rule=self.tap_rule)
         return super(FilterBlur, self)._process_frame(out)
 
 
@@ -730,7 +736,7 @@ class FilterAnalysisChain(_SequentialStateFilter):
     def __init__(self, source, background="mean", rate=0.02, sigma=5.0, threshold=20,
                  morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4,
                  output="mask", batch=32, max_labels=0, extra_outputs=(), static_background=None,
-                 prepare=None, size=None):
+                 prepare=None, size=None, tap_rule="cv4"):
         if source.is_color and prepare is None:
             raise ValueError("FilterAnalysisChain expects a monochrome video")
         if output not in ("mask", "labels", "filtered"):
@@ -745,7 +751,7 @@ class FilterAnalysisChain(_SequentialStateFilter):
         self._engine_args = dict(size=source.size if size is None else size, channels=1, dtype=np.uint8,
                                  max_batch=self.batch, background=background, bg_rate=rate, sigma=sigma,
                                  thresh=threshold, morphology=morphology, connectivity=connectivity,
-                                 max_labels=max_labels, prepare=prepare)
+                                 max_labels=max_labels, prepare=prepare, tap_rule=tap_rule)
         self._engine = None
         self._cache = {}            # frame index -> dict of per-frame results
         self.last_count = None

@@ -6,6 +6,8 @@ the GPU through ``libvideoanalysis_hip.so`` -- nothing is computed with NumPy.
 """
 import ctypes as C
 
+import threading
+
 import numpy as np
 
 from . import _hip
@@ -17,6 +19,7 @@ from ._hip import DeviceBuffer, check
 # are recycled by size class (powers of two) instead; the pool is bounded and trimmed on overflow.
 _POOL = {}
 _POOL_BYTES = 0
+_POOL_LOCK = threading.Lock()       # VideoPreprocessor runs these ops from one worker thread per function
 POOL_CAPACITY = 4 << 30
 
 
@@ -24,10 +27,11 @@ def _take(nbytes):
     """a device buffer of at least `nbytes` bytes (recycled when one of its size class is free)"""
     global _POOL_BYTES
     size = max(256, 1 << max(int(nbytes) - 1, 1).bit_length())
-    free = _POOL.get(size)
-    if free:
-        _POOL_BYTES -= size
-        return free.pop()
+    with _POOL_LOCK:
+        free = _POOL.get(size)
+        if free:
+            _POOL_BYTES -= size
+            return free.pop()
     return DeviceBuffer(size)
 
 
@@ -44,21 +48,29 @@ def _give(*bufs):
     for b in bufs:
         if b is None:
             continue
-        if _POOL_BYTES + b.nbytes > POOL_CAPACITY:
+        with _POOL_LOCK:
+            keep = _POOL_BYTES + b.nbytes <= POOL_CAPACITY
+            if keep:
+                _POOL.setdefault(b.nbytes, []).append(b)
+                _POOL_BYTES += b.nbytes
+        if not keep:
             b.free()
-            continue
-        _POOL.setdefault(b.nbytes, []).append(b)
-        _POOL_BYTES += b.nbytes
 
 
 def pool_clear():
-    """free every pooled buffer (tests; before handing the GPU to another library)"""
+    """free every pooled buffer (tests; before handing the GPU to another library) and let the
+    library's own scratch pool go back to the device (va_trim)"""
     global _POOL_BYTES
-    for free in _POOL.values():
-        for b in free:
-            b.free()
-    _POOL.clear()
-    _POOL_BYTES = 0
+    with _POOL_LOCK:
+        bufs = [b for free in _POOL.values() for b in free]
+        _POOL.clear()
+        _POOL_BYTES = 0
+    for b in bufs:
+        b.free()
+    try:
+        _hip.load_library().va_trim(0)
+    except Exception:
+        pass
 
 
 
@@ -81,12 +93,13 @@ def _hwc(frame_shape):
     raise ValueError("frames must be (H,W) or (H,W,C), got %r" % (frame_shape,))
 
 
-def gaussian_blur(frames, sigma, color=False, implementation=None):
+def gaussian_blur(frames, sigma, color=False, implementation=None, tap_rule="cv4"):
     """cv2.GaussianBlur(frame, (0,0), sigma) on uint8 or float32 frames
     (FilterBlur._process_frame, video/filters.py:388-392).
 
     frames: (H,W), (N,H,W); with color=True (H,W,C), (N,H,W,C).
     implementation: None (library's choice) or 'generic' (uint8 only, for cross-checks).
+    tap_rule (uint8 only): 'cv4' | 'cv3', see FilterBlur.
     """
     frames = np.asarray(frames)
     if frames.dtype not in (np.uint8, np.float32):
@@ -97,8 +110,13 @@ def gaussian_blur(frames, sigma, color=False, implementation=None):
     src = _upload(arr)
     dst = _take(arr.nbytes)
     if arr.dtype == np.uint8:
-        fn = {None: L.va_gaussian_u8, "generic": L.va_gaussian_u8_generic,
-              "valu": L.va_gaussian_u8_valu}[implementation]
+        if tap_rule != "cv4":
+            if implementation is not None:
+                raise ValueError("the implementation hooks run the default tap rule only")
+            fn = lambda *a: L.va_gaussian_u8_rule(*(a[:7] + (_hip.TAP_RULES[tap_rule],) + a[7:]))
+        else:
+            fn = {None: L.va_gaussian_u8, "generic": L.va_gaussian_u8_generic,
+                  "valu": L.va_gaussian_u8_valu}[implementation]
     else:
         fn = L.va_gaussian_f32
     check(fn(src.ptr, dst.ptr, n, h, w, c, float(sigma), None))
