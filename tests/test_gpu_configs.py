@@ -74,6 +74,43 @@ def _check_bg_blur_crops(oracle, clip, filtered, state, sigma, radius, size=96):
         assert np.array_equal(filtered[:, ya + y0:ya + y1, xa + x0:xa + x1], blur[:, y0:y1, x0:x1]), (ya, xa)
 
 
+def test_cfg1_480p_literal_clip_through_the_filter_classes(oracle):
+    """BASELINE.json configs[0], literally: seed 1, 64 frames of 640x480 uint8 (static N(100,10)
+    background + N(0,4) noise + 3 moving discs, r = 12..25, +60), VideoMemory -> FilterBackground ->
+    FilterBlur(sigma=2) -> FilterThreshold(20), read through the iterator protocol -- contracted into
+    one engine and filter by filter -- against the oracle, frame for frame."""
+    from video import filters as F
+    from video.io.memory import VideoMemory
+    rng = np.random.default_rng(1)
+    n, h, w = 64, 480, 640
+    base = np.clip(rng.normal(100, 10, (h, w)), 0, 255)
+    yy, xx = np.mgrid[:h, :w]
+    pos, vel, rad = rng.uniform(0, 1, (3, 2)) * (w, h), rng.uniform(-4, 4, (3, 2)), rng.uniform(12, 25, 3)
+    clip = np.empty((n, h, w), np.uint8)
+    for t in range(n):
+        f = base + rng.normal(0, 4, (h, w))
+        for (cx, cy), r in zip(pos + vel * t, rad):
+            f[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] += 60
+        clip[t] = np.clip(f, 0, 255).astype(np.uint8)
+    diff, mean = oracle.bg_mean_u8(clip)
+    ref = oracle.threshold_u8(oracle.gaussian_u8(diff, 2.0), 20)
+    assert 0 < (ref != 0).mean() < 0.2
+    for contract in (True, False):
+        F._GpuStage.contract = contract
+        try:
+            bg = F.FilterBackground(VideoMemory(clip))
+            video = F.FilterThreshold(F.FilterBlur(bg, 2), 20)
+            assert len(video) == n and video.size == (w, h) and not video.is_color
+            assert (video._runner() is not None) == contract
+            for k, frame in enumerate(video):
+                assert frame.dtype == np.uint8 and np.array_equal(frame, ref[k]), (contract, k)
+            assert k == n - 1
+            assert np.array_equal(video[17], ref[17]) and np.array_equal(video[-1], ref[-1])
+            video.close()
+        finally:
+            F._GpuStage.contract = True
+
+
 def test_cfg2_1080p_blur_threshold_mask_only(oracle):
     """BASELINE.json configs[1]: 1920x1080 uint8, batch 256, bg-sub + sigma=5 + threshold."""
     n, h, w = 256, 1080, 1920

@@ -924,6 +924,68 @@ def test_contour_moments_match_oracle_bit_for_bit(ops, oracle):
     assert np.array_equal(mom, [ref[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03")])
 
 
+def test_background_property_is_the_same_contracted_or_not(oracle):
+    """FilterBackground.background after k frames read through Threshold(Blur(Background(v))): the
+    fused chain works a batch ahead of the reader, the property still reports the state after the
+    frames READ so far -- equal to the per-filter path and to the oracle, mid-batch and after a seek"""
+    from video import filters as F
+    from video.io.memory import VideoMemory
+    clip = _blob_clip(50, 48, 64, seed=31)
+    states = {}
+    for contract in (True, False):
+        old = F._GpuStage.contract
+        F._GpuStage.contract = contract
+        try:
+            bg = F.FilterBackground(VideoMemory(clip))
+            thr = F.FilterThreshold(F.FilterBlur(bg, 2), 20)
+            assert (thr._runner() is not None) == contract
+            got = []
+            for k, _f in enumerate(thr):
+                if k in (0, 6, 31, 32, 40):
+                    got.append(np.array(bg.background))
+            thr[10]                                    # random access: the state follows the reader
+            got.append(np.array(bg.background))
+            states[contract] = got
+            thr.close()
+        finally:
+            F._GpuStage.contract = old
+    for k, a, b in zip((1, 7, 32, 33, 41, 11), states[True], states[False]):
+        _, ref = oracle.bg_mean_u8(clip[:k])
+        assert np.array_equal(a, ref), "contracted, after %d frames" % k
+        assert np.array_equal(b, ref), "per filter, after %d frames" % k
+
+
+def test_pooled_ops_from_several_threads(ops, oracle):
+    """VideoPreprocessor runs GPU callables from one worker thread per function: the device-buffer pool
+    of video.ops is shared between them (same frame size -> same size class)"""
+    import threading
+    rng = np.random.default_rng(8)
+    frames = rng.integers(0, 256, (24, 96, 128), dtype=np.uint8)
+    ref_blur = oracle.gaussian_u8(frames, 2.0)
+    ref_thr = oracle.threshold_u8(frames, 128)
+    ops.pool_clear()
+    errors = []
+
+    def work(fn, ref):
+        try:
+            for _ in range(3):
+                for k in range(frames.shape[0]):
+                    if not np.array_equal(fn(frames[k]), ref[k]):
+                        errors.append("mismatch at frame %d" % k)
+        except Exception as e:                        # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(lambda f: ops.gaussian_blur(f, 2.0), ref_blur)),
+               threading.Thread(target=work, args=(lambda f: ops.threshold(f, 128), ref_thr)),
+               threading.Thread(target=work, args=(lambda f: ops.gaussian_blur(f, 2.0), ref_blur))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    ops.pool_clear()
+
+
 def test_gpu_filter_chains_contract_into_one_engine(oracle):
     """consecutive GPU filters collapse into one FrameEngine with batched prefetch (the reference's
     own idiom for consecutive crops, video/filters.py:209-215 there): identical frames with and
@@ -990,26 +1052,45 @@ def test_gpu_filter_chains_contract_into_one_engine(oracle):
     assert np.array_equal(np.stack([np.array(f) for f in t1]), m1)
 
 
-def test_contracted_chain_speed_1080p():
-    """the four-filter chain over 256 x 1080p frames, read frame by frame, must cost about what
-    FilterAnalysisChain costs (one engine pass per 32 frames either way): within 1.5x"""
+def test_contracted_chain_runs_one_engine_pass_per_batch_1080p():
+    """the four-filter chain over 256 x 1080p frames, read frame by frame, must do what
+    FilterAnalysisChain does: ONE engine pass per 32 frames and no per-filter kernels -- checked by
+    counting engine passes (a property of the code, not of the clock; the timings of the three ways
+    to run the chain are printed for DESIGN.md and measured properly by tools/bench_next_tier.py)"""
     import time
     from video import filters as F
+    from video.engine import FrameEngine
     from video.io.memory import VideoMemory
     clip = _blob_clip(32, 1080, 1920, seed=5, nblobs=20, salt=0.002)
     clip = np.concatenate([clip] * 8)                      # 256 frames
+    passes = []
+    real_run = FrameEngine.run
+
+    def counting_run(self, frames, want=("mask", "labels", "counts")):
+        passes.append(len(frames))
+        return real_run(self, frames, want)
+
     def run(video):
         t0 = time.perf_counter()
         acc = 0
         for f in video:
             acc += int(f[540, 960])
         return time.perf_counter() - t0, acc
-    fused = F.FilterAnalysisChain(VideoMemory(clip), sigma=5.0, threshold=20, connectivity=0, batch=32)
-    run(fused)                                             # warm-up (engine creation, first touch)
-    t_fused, a = run(fused)
-    chain = F.FilterMorphology(F.FilterThreshold(F.FilterBlur(F.FilterBackground(VideoMemory(clip)), 5), 20), "close", 5)
-    run(chain)
-    t_chain, b = run(chain)
+
+    FrameEngine.run = counting_run
+    try:
+        fused = F.FilterAnalysisChain(VideoMemory(clip), sigma=5.0, threshold=20, connectivity=0, batch=32)
+        run(fused)                                             # warm-up (engine creation, first touch)
+        del passes[:]
+        t_fused, a = run(fused)
+        passes_fused = list(passes)
+        chain = F.FilterMorphology(F.FilterThreshold(F.FilterBlur(F.FilterBackground(VideoMemory(clip)), 5), 20), "close", 5)
+        run(chain)
+        del passes[:]
+        t_chain, b = run(chain)
+        passes_chain = list(passes)
+    finally:
+        FrameEngine.run = real_run
     F._GpuStage.contract = False
     try:
         plain = F.FilterMorphology(F.FilterThreshold(F.FilterBlur(F.FilterBackground(VideoMemory(clip[:32])), 5), 20), "close", 5)
@@ -1019,7 +1100,7 @@ def test_contracted_chain_speed_1080p():
     print("\n[chain contraction] 256 x 1080p: FilterAnalysisChain %.3f s, four contracted filters %.3f s, "
           "uncontracted %.3f s per 256 frames" % (t_fused, t_chain, t_plain * 8))
     assert a == b
-    assert t_chain < 1.5 * t_fused + 0.05
+    assert passes_fused == [32] * 8 and passes_chain == [32] * 8
 
 
 @pytest.mark.parametrize("mode", ["nearest", "linear", "cubic", "area"])

@@ -12,6 +12,8 @@ through the C ABI of libvideoanalysis_hip.so; there is no NumPy fallback.
 """
 import logging
 
+import weakref
+
 import numpy as np
 
 from . import ops
@@ -298,7 +300,7 @@ class _GpuStage(object):
         for st in stages[:-1]:
             if st._listeners and id(st) not in provides:
                 return None                 # its frames never exist in the fused chain
-        return dict(root=root, args=args, maxval=maxval, output=provides[id(self)],
+        return dict(root=root, args=args, maxval=maxval, output=provides[id(self)], stages=stages,
                     notify=[(st, provides[id(st)]) for st in stages[:-1] if st._listeners])
 
     def _runner(self):
@@ -318,9 +320,12 @@ class _GpuStage(object):
                     plan["root"], background=a["background"], rate=a["rate"], sigma=a["sigma"],
                     threshold=a["threshold"], morphology=a["morphology"], connectivity=0,
                     output=plan["output"], batch=self.chain_batch, extra_outputs=extra,
-                    static_background=a["static_background"], prepare=a["prepare"], size=a["size"])
+                    static_background=a["static_background"], prepare=a["prepare"], size=a["size"],
+                    tap_rule=a["tap_rule"])
                 self._runner_obj._engine_args["maxval"] = plan["maxval"]
                 self._runner_notify = plan["notify"]
+                for st in plan["stages"]:           # (a stage asked for its own state finds the reader)
+                    st._contracted_reader = weakref.ref(self)
             self._runner_key = key
         return self._runner_obj
 
@@ -332,6 +337,7 @@ class _GpuStage(object):
             return None
         for stage, kind in self._runner_notify:
             VideoBase._process_frame(stage, runner.last_results[kind])
+        self._contracted_pos = index + 1            # frames [0, index] have gone through the chain
         return VideoBase._process_frame(self, frame)
 
     def _disable(self):
@@ -713,7 +719,24 @@ class FilterBackground(_GpuStage, _SequentialStateFilter):
 
     @property
     def background(self):
-        """current background model (float64 / float32 array)"""
+        """current background model (float64 / float32 array): the state after the frames read so far.
+        When this filter runs as a stage of a contracted chain (its frames come out of a fused engine
+        that works a batch ahead) the state is brought to the reader's position with the state update
+        alone on this filter's own model -- the same arithmetic, so contracted and per-filter reads
+        report the same background."""
+        ref = getattr(self, "_contracted_reader", None)
+        reader = ref() if ref is not None else None
+        if reader is not None and getattr(reader, "_runner_obj", None) is not None and self.mode != "static":
+            pos = getattr(reader, "_contracted_pos", 0)
+            have = getattr(self, "_state_pos", None)
+            if self._model is None or have is None or have > pos:
+                self._seek_state(pos)
+            elif have < pos:
+                for a in range(have, pos, 32):
+                    self._advance_state(np.stack([np.asarray(self._source.get_frame(k))
+                                                  for k in range(a, min(pos, a + 32))]))
+                self._state_pos = pos
+            return self._model.state
         if self._model is None:
             self._reset_state()
             self._state_pos = 0

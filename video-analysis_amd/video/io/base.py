@@ -19,11 +19,18 @@ class SynchronizationError(RuntimeError):
     """raised when consumers of a shared video drift apart (base.py:22)"""
 
 
-class VideoBase(object):
-    """A sequence of equally sized frames with a cursor (`frame_pos`) and listeners.
+def _wrap_index(index, count):
+    """Python's negative-index convention for frame numbers"""
+    return index + count if index < 0 else index
 
-    Listeners are callables invoked with every frame the video hands out
-    (reference: video/io/base.py:137-145, 182-189)."""
+
+class VideoBase(object):
+    """A finite sequence of equally sized frames plus a read cursor.
+
+    The protocol every consumer of the reference relies on (video/io/base.py:26-269): `size` is
+    (width, height), `frame_count`, `fps`, `is_color`; frames come out of `get_frame(i)` (random
+    access) or `get_next_frame()` (cursor), both routed through `_process_frame`, which is where
+    listeners -- callables registered with `register_listener` -- see every frame handed out."""
 
     write_access = False
     seekable = False
@@ -31,57 +38,48 @@ class VideoBase(object):
     def __init__(self, size=(0, 0), frame_count=-1, fps=None, is_color=True):
         if len(size) != 2:
             raise ValueError("Videos must have two spatial dimensions.")
-        self.size = tuple(size)                  # (width, height)
+        self.size = tuple(size)
         self.frame_count = frame_count
-        self.fps = 25 if fps is None else fps
+        self.fps = fps if fps is not None else 25
         self.is_color = is_color
         self._listeners = []
-        self._frame_pos = 0                      # index of the frame handed out next
+        self._frame_pos = 0                      # the frame get_next_frame() returns next
 
-    # ------------------------------------------------------------------ description
+    # ---- format ------------------------------------------------------------------------------
+    width = property(lambda self: self.size[0])
+    height = property(lambda self: self.size[1])
+    bounds = property(lambda self: (0, 0) + tuple(self.size), doc="(left, top, width, height) of a frame")
+
+    @property
+    def shape(self):
+        """(frames, height, width) -- plus a trailing 3 for colour videos"""
+        w, h = self.size
+        return (self.frame_count, h, w, 3) if self.is_color else (self.frame_count, h, w)
+
+    @property
+    def video_format(self):
+        """the constructor arguments that describe this video's format"""
+        return dict(size=self.size, frame_count=self.frame_count, fps=self.fps, is_color=self.is_color)
+
+    def __len__(self):
+        return self.frame_count
+
     def get_property_list(self):
-        return ("size=(%d, %d)" % tuple(self.size), "frame_count=%s" % self.frame_count,
-                "fps=%s" % self.fps, "is_color=%s" % self.is_color)
+        fmt = self.video_format
+        return ("size=(%d, %d)" % tuple(fmt["size"]),) + tuple("%s=%s" % (k, fmt[k])
+                                                                for k in ("frame_count", "fps", "is_color"))
 
     def _listener_suffix(self):
-        k = len(self._listeners)
-        return "" if k == 0 else ("[1 listener]" if k == 1 else "[%d listeners]" % k)
+        n = len(self._listeners)
+        return "[%d listener%s]" % (n, "" if n == 1 else "s") if n else ""
 
     def __str__(self):
-        return "%s(%s)%s" % (type(self).__name__, ", ".join(self.get_property_list()),
-                             self._listener_suffix())
+        return "%s(%s)%s" % (type(self).__name__, ", ".join(self.get_property_list()), self._listener_suffix())
 
     def info(self):
         return "Video(%s)" % ", ".join(self.get_property_list())
 
-    # ------------------------------------------------------------------ geometry
-    def __len__(self):
-        return self.frame_count
-
-    @property
-    def width(self):
-        return self.size[0]
-
-    @property
-    def height(self):
-        return self.size[1]
-
-    @property
-    def bounds(self):
-        return (0, 0, self.width, self.height)
-
-    @property
-    def shape(self):
-        """shape of the whole video as an array: (frames, height, width[, 3])"""
-        shape = (self.frame_count, self.size[1], self.size[0])
-        return shape + (3,) if self.is_color else shape
-
-    @property
-    def video_format(self):
-        return {"size": self.size, "frame_count": self.frame_count, "fps": self.fps,
-                "is_color": self.is_color}
-
-    # ------------------------------------------------------------------ listeners
+    # ---- listeners ---------------------------------------------------------------------------
     def register_listener(self, listener_callback):
         self._listeners.append(listener_callback)
 
@@ -89,33 +87,35 @@ class VideoBase(object):
         self._listeners.remove(listener_callback)
 
     def _process_frame(self, frame):
-        """hook every frame passes through on its way out: notifies the listeners"""
-        for listener in self._listeners:
-            listener(frame)
+        """every outgoing frame passes here; subclasses transform it and call up"""
+        for notify in self._listeners:
+            notify(frame)
         return frame
 
-    # ------------------------------------------------------------------ cursor
+    # ---- cursor ------------------------------------------------------------------------------
     def get_frame_pos(self):
         return self._frame_pos
 
     def set_frame_pos(self, index):
-        if index < 0:
-            index += self.frame_count
-        if self.seekable:
-            if not 0 <= index < self.frame_count:
-                raise IndexError("Seeking to frame %d was not possible." % index)
-            self._frame_pos = index
-        elif index >= self.get_frame_pos():
-            for _ in range(self.get_frame_pos(), index):     # fast-forward
+        """random-access videos jump; forward-only ones read and drop frames up to `index` and
+        refuse to go back (NotSeekableError)"""
+        target = _wrap_index(index, self.frame_count)
+        if not self.seekable:
+            here = self.get_frame_pos()
+            if target < here:
+                raise NotSeekableError("Cannot seek to frame %d, because the video is already at "
+                                       "frame %d" % (target, here))
+            for _ in range(target - here):
                 self.get_next_frame()
+        elif 0 <= target < self.frame_count:
+            self._frame_pos = target
         else:
-            raise NotSeekableError("Cannot seek to frame %d, because the video is already at "
-                                   "frame %d" % (index, self.get_frame_pos()))
+            raise IndexError("Seeking to frame %d was not possible." % target)
 
     def rewind(self):
         self.set_frame_pos(0)
 
-    # ------------------------------------------------------------------ frame access
+    # ---- frames ------------------------------------------------------------------------------
     def get_frame(self, index):
         raise NotImplementedError
 
@@ -137,30 +137,30 @@ class VideoBase(object):
         return VideoIterator(self)
 
     def __getitem__(self, key):
-        if isinstance(key, slice):
-            return VideoSlice(self, *key.indices(self.frame_count), _normalized=True)
         if isinstance(key, (int, np.integer)):
             return self.get_frame(int(key))
+        if isinstance(key, slice):
+            return VideoSlice(self, *key.indices(self.frame_count), _normalized=True)
         raise TypeError("Invalid key `%r` for indexing" % (key,))
 
     def __setitem__(self, key, value):
         raise ValueError("Writing to this video stream is prohibited.")
 
     def copy(self, dtype=np.uint8, disp=False):
-        """materialise the video as a VideoMemory (base.py:248-269)"""
+        """reads the whole video into a VideoMemory (reference: base.py:248-269)"""
         from .memory import VideoMemory
-        data = np.empty(self.shape, dtype)
-        for k, frame in enumerate(self):
-            data[k, ...] = frame
-        return VideoMemory(data, fps=self.fps, copy_data=False)
+        frames = np.empty(self.shape, dtype)
+        for slot, frame in zip(frames, self):
+            slot[...] = frame
+        return VideoMemory(frames, fps=self.fps, copy_data=False)
 
 
 class VideoIterator(object):
-    """iterator protocol for videos; rewinds the video when created (base.py:273-283)"""
+    """what `iter(video)` returns: starts at frame 0 and ends when the video does (base.py:273-283)"""
 
     def __init__(self, video):
+        video.rewind()
         self._video = video
-        self._video.rewind()
 
     def __iter__(self):
         return self
@@ -171,20 +171,19 @@ class VideoIterator(object):
         except IndexError:
             raise StopIteration
 
-    next = __next__         # Python-2 spelling used by reference-era callers
+    next = __next__         # the spelling reference-era (Python 2) callers use
 
 
 class VideoFilterBase(VideoBase):
-    """A view on another video that transforms each frame in `_process_frame`
-    (reference: video/io/base.py:313-388).  Format properties default to the source's."""
+    """A video computed from another one, frame by frame: subclasses override `_process_frame`
+    (reference: video/io/base.py:313-388).  Whatever of the format is not given is the source's."""
 
     def __init__(self, source, size=None, frame_count=None, fps=None, is_color=None):
         self._source = source
-        super(VideoFilterBase, self).__init__(
-            size=source.size if size is None else size,
-            frame_count=source.frame_count if frame_count is None else frame_count,
-            fps=source.fps if fps is None else fps,
-            is_color=source.is_color if is_color is None else is_color)
+        fmt = dict(source.video_format)
+        given = dict(size=size, frame_count=frame_count, fps=fps, is_color=is_color)
+        fmt.update({k: v for k, v in given.items() if v is not None})
+        super(VideoFilterBase, self).__init__(**fmt)
 
     def __str__(self):
         return "%s +%s%s" % (self._source, type(self).__name__, self._listener_suffix())
@@ -196,28 +195,26 @@ class VideoFilterBase(VideoBase):
     def abort_iteration(self):
         self._source.abort_iteration()
 
-    def set_frame_pos(self, index):
-        if index < 0:
-            index += self.frame_count
-        self._source.set_frame_pos(index)
-        self._frame_pos = index
-
     def get_frame_pos(self):
         return self._source.get_frame_pos()
 
+    def set_frame_pos(self, index):
+        self._frame_pos = _wrap_index(index, self.frame_count)
+        self._source.set_frame_pos(self._frame_pos)
+
     def get_frame(self, index):
-        if index < 0:
-            index += self.frame_count
-        frame = self._source.get_frame(index)
+        index = _wrap_index(index, self.frame_count)
+        raw = self._source.get_frame(index)
         self._frame_pos = index
-        return self._process_frame(frame)
+        return self._process_frame(raw)
 
     def get_next_frame(self):
-        frame = self._source.get_next_frame()
+        raw = self._source.get_next_frame()
         self._frame_pos += 1
-        return self._process_frame(frame)
+        return self._process_frame(raw)
 
     def close(self, propagate=True):
+        """closes the source; with `propagate` the whole chain of filters below it"""
         if propagate and isinstance(self._source, VideoFilterBase):
             self._source.close(propagate=True)
         else:
@@ -225,77 +222,70 @@ class VideoFilterBase(VideoBase):
 
 
 class VideoSlice(VideoFilterBase):
-    """video[start:stop:step] (reference: video/io/base.py:392-474)"""
+    """`video[start:stop:step]` (reference: video/io/base.py:392-474).  The selection is a Python
+    `range` over the source's frame numbers: frame k of the slice is frame `self._frames[k]` there."""
 
     def __init__(self, source, start=0, stop=None, step=1, _normalized=False):
-        count = source.frame_count
-        if _normalized:             # start/stop come from slice.indices(): use them verbatim
-            self._start, self._stop = start, stop   # (stop == -1 with step < 0: down to frame 0)
-        else:
-            self._start = start if start >= 0 else count + start
-            if stop is None:
-                self._stop = count
-            else:
-                self._stop = stop if stop >= 0 else count + stop
         if step == 0:
             raise ValueError("step argument must not be zero.")
-        self._step = step
-        frame_count = max(0, int(np.ceil((self._stop - self._start) / self._step)))
-        if frame_count > 0:
-            source.set_frame_pos(self._start)
-        super(VideoSlice, self).__init__(source, frame_count=frame_count)
+        if _normalized:             # start/stop/step come from slice.indices(): use them verbatim
+            self._frames = range(start, stop, step)         # (stop == -1 with step < 0: down to frame 0)
+        else:
+            count = source.frame_count
+            self._frames = range(_wrap_index(start, count), count if stop is None else _wrap_index(stop, count), step)
+        if len(self._frames):
+            source.set_frame_pos(self._frames[0])
+        super(VideoSlice, self).__init__(source, frame_count=len(self._frames))
         if step < 0:
             logger.warning("Reversing a video can slow down the processing significantly.")
 
-    def _check(self, index):
-        if index < 0:
-            index += self.frame_count
+    def _source_index(self, index):
+        index = _wrap_index(index, self.frame_count)
         if not 0 <= index < self.frame_count:
-            raise IndexError("Cannot access frame %d in video of length %d"
-                             % (index, self.frame_count))
-        return index
+            raise IndexError("Cannot access frame %d in video of length %d" % (index, self.frame_count))
+        return index, self._frames[index]
+
+    def get_frame_pos(self):
+        return self._frame_pos
 
     def set_frame_pos(self, index):
         if self.frame_count == 0 and index == 0:      # rewinding an empty slice is a no-op
             self._frame_pos = 0
             return
-        index = self._check(index)
-        self._source.set_frame_pos(self._start + index * self._step)
-        self._frame_pos = index
-
-    def get_frame_pos(self):
-        return self._frame_pos
+        self._frame_pos, there = self._source_index(index)
+        self._source.set_frame_pos(there)
 
     def get_frame(self, index):
-        index = self._check(index)
-        return self._process_frame(self._source.get_frame(self._start + index * self._step))
+        _, there = self._source_index(index)
+        return self._process_frame(self._source.get_frame(there))
 
     def get_next_frame(self):
         if self._frame_pos >= self.frame_count:
             self.abort_iteration()
             raise StopIteration
-        if self._step == 1:
-            frame = self._source.get_next_frame()
+        if self._frames.step == 1:                    # consecutive frames: let the source stream
+            raw = self._source.get_next_frame()
         else:
-            frame = self._source.get_frame(self._start + self._frame_pos * self._step)
+            raw = self._source.get_frame(self._frames[self._frame_pos])
         self._frame_pos += 1
-        return self._process_frame(frame)
+        return self._process_frame(raw)
 
 
 class _VideoForkClient(VideoBase):
-    """one consumer of a VideoFork: iterating it asks the fork for frame `_frame_pos`
-    (reference: video/io/base.py:478-513)"""
+    """one reader of a VideoFork (reference: video/io/base.py:478-513).  It holds no frames: every
+    read goes to the fork, which knows which of its readers has taken the frame it holds."""
 
     def __init__(self, video_fork):
         self._parent = video_fork
         super(_VideoForkClient, self).__init__(**video_fork.video_format)
 
     def get_next_frame(self):
-        frame = self._parent.get_frame(self._frame_pos)
+        frame = self._parent._serve(self, self._frame_pos)      # StopIteration past the last frame
         self._frame_pos += 1
-        if frame is StopIteration:
-            raise StopIteration
         return frame
+
+    def get_frame(self, index):
+        raise NotSeekableError("clients of a VideoFork read forward only (the fork holds one frame)")
 
     def set_frame_pos(self, index):
         self._frame_pos = index + self.frame_count if index < 0 else index
@@ -305,89 +295,112 @@ class _VideoForkClient(VideoBase):
         super(_VideoForkClient, self).abort_iteration()
 
     def close(self):
-        """asks the fork to send SystemExit to all clients"""
+        """a reader that closes ends the iteration of every other reader (SystemExit there)"""
         self._parent.abort_iteration()
 
 
 class VideoFork(VideoFilterBase):
-    """hands the frames of one video to several consumers that are iterated in lock step
-    (reference: video/io/base.py:516-662):
+    """One video, several readers in lock step (reference: video/io/base.py:516-662):
 
         fork = VideoFork(video)
         a, b = FilterBlur(fork.get_client(), 2), FilterCrop(fork.get_client(), region='left')
         for frame_a, frame_b in zip(a, b):
             ...
 
-    Every frame is pulled from the source once and cached until the next one is asked for.  With
-    `synchronized` a client that runs ahead of the others raises SynchronizationError (the test
-    counts how often the cached frame has been handed out); a client asking for any frame but
-    the cached or the next one always does."""
+    The fork pulls every frame from its source once and HOLDS it until a reader asks for the next
+    one.  Book-keeping is per reader -- the set of readers that have taken the held frame -- so
+    `synchronized` means: the next frame is pulled only once every reader has had the held one
+    (SynchronizationError for a reader that runs ahead), and a reader that asks twice for the same
+    frame is still one reader.  Any request for a frame other than the held one or its successor is
+    a SynchronizationError: the fork cannot go back and will not skip.  The GPU counterpart of this
+    1 -> N fan-out -- one upload, several device-side consumers -- is `video.streaming`."""
 
     def __init__(self, source, synchronized=True, client_count=None):
-        self.synchronized = synchronized
-        self._client_count = client_count
+        self.synchronized = bool(synchronized)
+        self._fixed_clients = client_count      # None: as many readers as register
         self._clients = []
-        self._frame = None
-        self._frame_index = -1
-        self._retrieve_count = np.inf          # how often the cached frame has been handed out
-        self.state = "normal"
+        self._held = None                       # frame most recently pulled from the source
+        self._held_index = -1                   # its index; the successor is _held_index + 1
+        self._taken_by = None                   # ids of the readers that have the held frame (None: nothing held)
+        self._exhausted = False                 # the source ended: the successor does not exist
+        self._aborted = False
         super(VideoFork, self).__init__(source)
 
+    # -- what the reference exposes -------------------------------------------------------------
     @property
     def client_count(self):
-        return len(self._clients) if self._client_count is None else self._client_count
+        return len(self._clients) if self._fixed_clients is None else self._fixed_clients
+
+    @property
+    def state(self):
+        return "aborting" if self._aborted else "normal"
+
+    def get_client(self):
+        """a new reader; iterate it (or a filter chain on top of it)"""
+        if self._fixed_clients is not None and len(self._clients) >= self._fixed_clients:
+            raise ValueError("this fork was created for %d readers and has them all" % self._fixed_clients)
+        reader = _VideoForkClient(self)
+        self._clients.append(reader)
+        self._taken_by = None                   # a late joiner must not block (or be blocked by) the held frame
+        return reader
+
+    def __iter__(self):
+        raise RuntimeError("a VideoFork is not iterated itself: iterate the readers from get_client()")
+
+    # -- serving ---------------------------------------------------------------------------------
+    def _pull(self):
+        try:
+            self._held = self.get_next_frame()          # (listeners of the fork see every frame once)
+            self._exhausted = False
+        except (StopIteration, IndexError):
+            self._held, self._exhausted = None, True
+        self._held_index += 1
+        self._taken_by = set()
+
+    def _serve(self, reader, index):
+        if self._aborted:
+            raise SystemExit("the iteration over this VideoFork was aborted by one of its readers")
+        if index < 0:
+            index += self.frame_count
+        ahead = index - self._held_index
+        if ahead == 1:
+            waiting = self.synchronized and self._taken_by is not None and \
+                len(self._taken_by) < self.client_count
+            if waiting:
+                raise SynchronizationError("frame %d has not been read by all %d readers yet; frame %d "
+                                           "cannot be pulled" % (self._held_index, self.client_count, index))
+            self._pull()
+        elif ahead != 0:
+            raise SynchronizationError("the fork holds frame %d and can only move on to frame %d, but frame "
+                                       "%d was requested: its readers are out of step"
+                                       % (self._held_index, self._held_index + 1, index))
+        if self._taken_by is not None:
+            self._taken_by.add(id(reader))
+        if self._exhausted:
+            raise StopIteration
+        return self._held
+
+    def get_frame(self, index):
+        """frame `index` for an anonymous reader: the held frame or its successor (reference API)"""
+        try:
+            return self._serve(None, index)
+        except StopIteration:
+            return StopIteration
 
     def set_frame_pos(self, index):
-        """positions the fork and all of its clients"""
+        """moves the fork and all of its readers to frame `index`"""
         if index < 0:
             index += self.frame_count
         super(VideoFork, self).set_frame_pos(index)
-        for client in self._clients:
-            client.set_frame_pos(index)
-        self._frame = None
-        self._frame_index = index - 1
-
-    def get_frame(self, index):
-        """frame `index` for a client: the cached frame, or the next one of the source"""
-        if self.state == "aborting":
-            raise SystemExit("Another client of the VideoFork requested to abort the iteration.")
-        if index < 0:
-            index += self.frame_count
-        if index == self._frame_index:
-            self._retrieve_count += 1
-        elif index == self._frame_index + 1:
-            if self.synchronized and self._retrieve_count < self.client_count:
-                raise SynchronizationError("The other clients have not yet read the previous frame.")
-            self._frame_index = index
-            try:
-                self._frame = self.get_next_frame()
-            except (StopIteration, IndexError):
-                self._frame = StopIteration
-            self._retrieve_count = 1
-        else:
-            raise SynchronizationError("The clients of the video fork ran out of sync. The parent "
-                                       "process is at frame %d, while one client requested frame %d"
-                                       % (self._frame_index, index))
-        return self._frame
+        for reader in self._clients:
+            reader.set_frame_pos(index)
+        self._held, self._held_index, self._taken_by, self._exhausted = None, index - 1, None, False
 
     def clear(self):
-        """ends the iteration and forgets all clients (they may still read the cached frame)"""
+        """forgets all readers (they may still read the held frame)"""
         self._clients = []
 
     def abort_iteration(self):
-        """sends SystemExit to all other clients"""
-        self.state = "aborting"
+        """every reader's next read raises SystemExit"""
+        self._aborted = True
         super(VideoFork, self).abort_iteration()
-
-    def __iter__(self):
-        raise RuntimeError("Cannot iterate over a VideoFork. Use the get_client() method to get an "
-                           "iterable client.")
-
-    def get_client(self):
-        """a new client that can be iterated"""
-        if self._client_count is not None and len(self._clients) >= self._client_count:
-            raise ValueError("We already registered %d clients." % self._client_count)
-        client = _VideoForkClient(self)
-        self._clients.append(client)
-        self._retrieve_count = np.inf
-        return client
