@@ -51,6 +51,7 @@ extern "C" {
 #define VA_U8 0
 #define VA_F32 1
 #define VA_F64 2 /* targets of va_normalize / va_gaussian_noise only */
+#define VA_I16 3 /* int16 frames (FilterTimeDifference's output): va_mean_any / va_welford_any only */
 /* background modes (BUILD-DEFINED FilterBackground; arithmetic of video/analysis/video.py) */
 #define VA_BG_NONE 0
 #define VA_BG_MEAN 1   /* cumulative mean, float64 state: measure_mean, video/analysis/video.py:33 */
@@ -135,6 +136,13 @@ int va_gauss_taps_f32(double sigma, int *ksize_out, float *taps_out, int capacit
  * dtype VA_U8 (all modes) or VA_F32 (EMA only).  diff_out may be NULL (state update only). */
 int va_bg_update(int mode, int dtype, const void *frames_dev, void *diff_out_dev,
                  void *state_dev, int64_t n_seen, double rate, int n, size_t px, void *stream);
+/* measure_mean / measure_mean_std over frames of any dtype the reference meets (video/analysis/video.py:26-55):
+ * dtype VA_U8, VA_I16 (FilterTimeDifference's int16) or VA_F32.  NumPy's promotions are kept:
+ * `frame/(n + 1)` is rounded to float32 first for float32 frames, float64 otherwise. */
+int va_mean_any(const void *frames_dev, int dtype, double *mean_dev, int64_t n_seen, int n, size_t px,
+                void *stream);
+int va_welford_any(const void *frames_dev, int dtype, double *mean_dev, double *m2_dev, int64_t n_seen,
+                   int n, size_t px, void *stream);
 /* replaces  measure_mean_std's Welford update, video/analysis/video.py:48-50 (float64 state) */
 int va_welford_u8(const uint8_t *frames_dev, double *mean_dev, double *m2_dev, int64_t n_seen,
                   int n, size_t px, void *stream);
@@ -189,14 +197,19 @@ int va_rot90(const void *src_dev, void *dst_dev, int n, int h, int w, int elem_b
  * c <= 4 interleaved channels.  OpenCV's 8-bit definitions: nearest = floor(x * src/dst); linear and
  * cubic (A = -0.75) with 11-bit fixed-point weights and OpenCV's rounding steps (an exact 2x2
  * linear shrink is the area mean, as there); area = block means for integer shrink factors,
- * float cell-overlap weights for other shrinks, linear with area-style positions when growing.
- * INTER_LANCZOS4 is not provided.  src != dst. */
+ * float cell-overlap weights for other shrinks, linear with area-style positions when growing;
+ * lanczos4 (video/filters.py:293-294) = 8 x 8 taps, 11-bit fixed point, int32 accumulation.  src != dst.
+ * va_resize_f32: float32 frames (FilterResize takes the video's dtype): the float instantiations of the
+ * same algorithms -- float coefficients, products summed from the first tap to the last, no rounding. */
 #define VA_INTER_NEAREST 0
 #define VA_INTER_LINEAR 1
 #define VA_INTER_CUBIC 2
 #define VA_INTER_AREA 3
+#define VA_INTER_LANCZOS4 4
 int va_resize_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int src_h, int src_w, int c, int dst_h,
                  int dst_w, int interpolation, void *stream);
+int va_resize_f32(const float *src_dev, float *dst_dev, int n, int src_h, int src_w, int c, int dst_h,
+                  int dst_w, int interpolation, void *stream);
 
 /* ------------------------------------------------------------------ A6 morphology
  * replaces  cv2.erode / cv2.dilate(img, cv2.getStructuringElement(shape, (k, k))),
@@ -271,6 +284,10 @@ int va_contour_moments(const void *points_dev, const int32_t *npoints_dev, int n
  *           img > maximum over the 8 neighbours.  dst: 0/1 u8 mask. */
 int va_detect_peaks_u8(const uint8_t *src_dev, uint8_t *dst_dev, int n, int h, int w,
                        int include_plateaus, void *stream);
+/* the same on float32 maps (the reference calls it on distance / correlation maps): comparisons in float,
+ * background = (img == 0) */
+int va_detect_peaks_f32(const float *src_dev, uint8_t *dst_dev, int n, int h, int w, int include_plateaus,
+                        void *stream);
 /* replaces  the python fallback of mask_thinning, video/analysis/image.py:243-258 (3x3 cross):
  *           eroded = cv2.erode(img); temp = cv2.dilate(eroded); cv2.subtract(img, temp, temp);
  *           cv2.bitwise_or(skel, temp, skel); img = eroded   ... until img is empty.
@@ -285,6 +302,12 @@ int va_mask_thinning_u8(uint8_t *img_dev, uint8_t *scratch_dev, uint8_t *skel_de
 int va_image_statistics_u8(const uint8_t *src_dev, double *mean_out_dev, double *var_out_dev, int n,
                            int h, int w, int kernel, int ksize, double prior, int exclude_center,
                            void *stream);
+
+/* float32 images: truncated towards zero like the reference's `img.astype(np.int) - prior`
+ * (video/analysis/image.py:175), then direct window sums in float64 */
+int va_image_statistics_f32(const float *src_dev, double *mean_out_dev, double *var_out_dev, int n,
+                            int h, int w, int kernel, int ksize, double prior, int exclude_center,
+                            void *stream);
 
 /* ------------------------------------------------------------------ fused pipeline
  * One handle per filter chain (not thread-safe; the reference's pull model is single-threaded,

@@ -74,6 +74,7 @@ def lib():
         _lib.vao_contour_area.argtypes = [C.c_void_p, C.c_int]
         _lib.vao_contour_area.restype = C.c_double
         _lib.vao_resize_u8.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7
+        _lib.vao_resize_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7
         _lib.vao_contour_moments.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.vao_contour_moments.restype = None
         _lib.vao_chain_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -183,6 +184,34 @@ def bg_mean_u8(frames, mean=None, n_seen=0, want_diff=True):
     diff = np.empty_like(a) if want_diff else None
     lib().vao_bg_mean_u8(_p(a), _p(diff), _p(mean), int(n_seen), a.shape[0], px)
     return diff, mean
+
+
+_ANY_DTYPES = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.int16): 3}
+
+
+def mean_any(frames, mean=None, n_seen=0):
+    """measure_mean's update (video/analysis/video.py:33) for uint8 / int16 / float32 frames"""
+    a = np.ascontiguousarray(frames)
+    px = int(np.prod(a.shape[1:]))
+    mean = np.zeros(a.shape[1:], np.float64) if mean is None else np.array(mean, np.float64)
+    fn = lib().vao_mean_any
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_size_t]
+    if fn(_p(a), _ANY_DTYPES[a.dtype], _p(mean), int(n_seen), a.shape[0], px):
+        raise TypeError("unsupported dtype %s" % a.dtype)
+    return mean
+
+
+def welford_any(frames, mean=None, m2=None, n_seen=0):
+    """measure_mean_std's update (video/analysis/video.py:48-50) for uint8 / int16 / float32 frames"""
+    a = np.ascontiguousarray(frames)
+    px = int(np.prod(a.shape[1:]))
+    mean = np.zeros(a.shape[1:], np.float64) if mean is None else np.array(mean, np.float64)
+    m2 = np.zeros(a.shape[1:], np.float64) if m2 is None else np.array(m2, np.float64)
+    fn = lib().vao_welford_any
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_size_t]
+    if fn(_p(a), _ANY_DTYPES[a.dtype], _p(mean), _p(m2), int(n_seen), a.shape[0], px):
+        raise TypeError("unsupported dtype %s" % a.dtype)
+    return mean, m2
 
 
 def welford_u8(frames, mean=None, m2=None, n_seen=0):
@@ -345,16 +374,21 @@ def contour_area(contour):
     return lib().vao_contour_area(_p(c), len(c))
 
 
-RESIZE_MODES = {"nearest": 0, "linear": 1, "cubic": 2, "area": 3}
+RESIZE_MODES = {"nearest": 0, "linear": 1, "cubic": 2, "area": 3, "lanczos": 4}
 
 
-def resize_u8(frames, size, interpolation="linear", layout=None):
+def resize_f32(frames, size, interpolation="linear", layout=None):
+    return resize_u8(frames, size, interpolation, layout, dtype=np.float32)
+
+
+def resize_u8(frames, size, interpolation="linear", layout=None, dtype=np.uint8):
     """cv2.resize(frame, (width, height), interpolation=...) per frame (FilterResize,
-    video/filters.py:310-314) for uint8 frames; size = (width, height)"""
-    a, n, h, w, c = _nhwc(np.asarray(frames, np.uint8), layout)
+    video/filters.py:310-314) for uint8 (or, dtype=np.float32, float32) frames; size = (width, height)"""
+    a, n, h, w, c = _nhwc(np.asarray(frames, dtype), layout)
     dw, dh = int(size[0]), int(size[1])
-    out = np.empty((n, dh, dw, c), np.uint8)
-    if lib().vao_resize_u8(_p(a), _p(out), n, h, w, c, dh, dw, RESIZE_MODES[interpolation]):
+    out = np.empty((n, dh, dw, c), dtype)
+    fn = lib().vao_resize_u8 if np.dtype(dtype) == np.uint8 else lib().vao_resize_f32
+    if fn(_p(a), _p(out), n, h, w, c, dh, dw, RESIZE_MODES[interpolation]):
         raise ValueError("resize failed")
     shape = a.shape[:-3] + (dh, dw) + ((c,) if a.ndim == 4 or layout == "hwc" else ())
     if a.ndim == 2:

@@ -37,6 +37,7 @@ void vao_label_batch_i32(const uint8_t *mask, int32_t *labels, int32_t *counts, 
 void vao_region_stats(const int32_t *labels, int h, int w, int count, int64_t *stats);
 void vao_contour_moments(const void *pts, int n, int is_float, double *out);
 int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw, int mode);
+int vao_resize_f32(const float *src, float *dst, int n, int sh, int sw, int c, int dh, int dw, int mode);
 
 static _Thread_local char g_err[256] = "";
 #define FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
@@ -205,6 +206,13 @@ int va_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c,
     (void)st;
     if (!src || !dst || src == dst) FAIL(VA_ERR_INVALID, "va_resize_u8: src/dst must be distinct non-NULL");
     if (vao_resize_u8(src, dst, n, sh, sw, c, dh, dw, mode)) FAIL(VA_ERR_INVALID, "va_resize_u8: bad argument");
+    return VA_OK;
+}
+int va_resize_f32(const float *src, float *dst, int n, int sh, int sw, int c, int dh, int dw, int mode, void *st)
+{
+    (void)st;
+    if (!src || !dst || src == dst) FAIL(VA_ERR_INVALID, "va_resize_f32: src/dst must be distinct non-NULL");
+    if (vao_resize_f32(src, dst, n, sh, sw, c, dh, dw, mode)) FAIL(VA_ERR_INVALID, "va_resize_f32: bad argument");
     return VA_OK;
 }
 int va_contour_moments(const void *points, const int32_t *npoints, int n, int max_points, int is_float,

@@ -287,6 +287,48 @@ void vao_bg_mean_u8(const uint8_t *frames, uint8_t *diff_out, double *mean, int6
     }
 }
 
+/* measure_mean / measure_mean_std for frames of dtype 0 = uint8, 3 = int16, 1 = float32 (the codes of the
+ * product's header).  NumPy's promotions are part of the definition (video/analysis/video.py:33, 48-50):
+ * `frame/(n + 1)` with a float32 frame and a Python int is a FLOAT32 quotient, which only then joins the
+ * float64 mean; integer frames divide in float64; Welford's `frame - mean` promotes the frame exactly. */
+static double vao_frame_value(const void *frames, int dtype, size_t i)
+{
+    return dtype == 0 ? (double)((const uint8_t *)frames)[i]
+         : dtype == 3 ? (double)((const int16_t *)frames)[i] : (double)((const float *)frames)[i];
+}
+int vao_mean_any(const void *frames, int dtype, double *mean, int64_t n_seen, int n, size_t px)
+{
+    if (dtype != 0 && dtype != 1 && dtype != 3)
+        return -1;
+    for (int f = 0; f < n; f++) {
+        double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
+        for (size_t i = 0; i < px; i++) {
+            double q;
+            if (dtype == 1)
+                q = (double)(((const float *)frames)[(size_t)f * px + i] / (float)dn1);
+            else
+                q = vao_frame_value(frames, dtype, (size_t)f * px + i) / dn1;
+            mean[i] = mean[i] * dn / dn1 + q;
+        }
+    }
+    return 0;
+}
+int vao_welford_any(const void *frames, int dtype, double *mean, double *m2, int64_t n_seen, int n, size_t px)
+{
+    if (dtype != 0 && dtype != 1 && dtype != 3)
+        return -1;
+    for (int f = 0; f < n; f++) {
+        double dn1 = (double)(n_seen + f + 1);
+        for (size_t i = 0; i < px; i++) {
+            double fr = vao_frame_value(frames, dtype, (size_t)f * px + i);
+            double delta = fr - mean[i];
+            mean[i] = mean[i] + delta / dn1;
+            m2[i] = m2[i] + delta * (fr - mean[i]);
+        }
+    }
+    return 0;
+}
+
 /* measure_mean_std (video/analysis/video.py:39-55), Welford:
  *   delta = frame - mean; mean = mean + delta/(n+1); M2 = M2 + delta*(frame - mean) */
 void vao_welford_u8(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
@@ -901,7 +943,11 @@ void vao_contour_moments(const void *pts, int n, int is_float, double *out)
  *   AREA     shrink by integer factors: block mean ((sum+2)>>2 for 2x2, else
  *            saturate_cast<uchar>(sum * (1.f/area))); other shrinks: float cell-overlap tables
  *            (computeResizeAreaTab order); growing: LINEAR with area-style positions
- * mode: 0 nearest, 1 linear, 2 cubic, 3 area.  Parity with real OpenCV: unpinned (no cv2 here).
+ *   LANCZOS4 8 x 8 taps (interpolateLanczos4: sines by angle addition, normalised in float), 11-bit
+ *            fixed point like CUBIC, int32 accumulation, (sum + 2^21) >> 22, replicated border
+ * mode: 0 nearest, 1 linear, 2 cubic, 3 area, 4 lanczos4.  Parity with real OpenCV: unpinned (no cv2).
+ * vao_resize_f32: the float32 instantiations of the same templates (float coefficients, products
+ * summed left to right in float without contraction, no rounding step at the end).
  * ---------------------------------------------------------------------------------- */
 static int vao_round_half_even(double v) { return (int)nearbyint(v); }
 static short vao_sat_short(float v)
@@ -917,6 +963,28 @@ static void vao_cubic_coeffs(float x, float *c)
     c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
     c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
     c[3] = 1.f - c[0] - c[1] - c[2];
+}
+static void vao_lanczos4_coeffs(float x, float *coeffs)
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    if (x < 1.1920928955078125e-07f) {          /* FLT_EPSILON */
+        for (int i = 0; i < 8; i++)
+            coeffs[i] = 0;
+        coeffs[3] = 1;
+        return;
+    }
+    float sum = 0;
+    const double pi = 3.1415926535897932384626433832795;
+    double y0 = -(double)(x + 3) * pi * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; i++) {
+        double y = -(double)(x + 3 - i) * pi * 0.25;
+        coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += coeffs[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++)
+        coeffs[i] *= sum;
 }
 typedef struct { int si, di; float alpha; } vao_dec_alpha;
 static int vao_area_tab(int ssize, int dsize, double scale, vao_dec_alpha *tab)
@@ -949,7 +1017,7 @@ static int vao_area_tab(int ssize, int dsize, double scale, vao_dec_alpha *tab)
 int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw,
                   int mode)
 {
-    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || c <= 0 || mode < 0 || mode > 3)
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || c <= 0 || mode < 0 || mode > 4)
         return -1;
     const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
     const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
@@ -1050,11 +1118,11 @@ int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c
     /* LINEAR / CUBIC (and AREA when growing = LINEAR with area-style positions) */
     const int area_mode = mode == 3;
     if (area_mode) mode = 1;
-    const int ksize = mode == 1 ? 2 : 4, ksize2 = ksize / 2;
+    const int ksize = mode == 1 ? 2 : mode == 2 ? 4 : 8, ksize2 = ksize / 2;
     int *xofs = (int *)malloc(sizeof(int) * (size_t)dw), *yofs = (int *)malloc(sizeof(int) * (size_t)dh);
     short *ialpha = (short *)malloc(sizeof(short) * (size_t)dw * ksize), *ibeta = (short *)malloc(sizeof(short) * (size_t)dh * ksize);
     int xmin = 0, xmax = dw;
-    float cbuf[4];
+    float cbuf[8];
     for (int dx = 0; dx < dw; dx++) {
         float fx;
         int sx;
@@ -1077,7 +1145,8 @@ int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c
         }
         xofs[dx] = sx;
         if (mode == 1) cbuf[0] = 1.f - fx, cbuf[1] = fx;
-        else vao_cubic_coeffs(fx, cbuf);
+        else if (mode == 2) vao_cubic_coeffs(fx, cbuf);
+        else vao_lanczos4_coeffs(fx, cbuf);
         for (int k = 0; k < ksize; k++)
             ialpha[dx * ksize + k] = vao_sat_short(cbuf[k] * 2048);
     }
@@ -1095,7 +1164,8 @@ int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c
         }
         yofs[dy] = sy;
         if (mode == 1) cbuf[0] = 1.f - fy, cbuf[1] = fy;
-        else vao_cubic_coeffs(fy, cbuf);
+        else if (mode == 2) vao_cubic_coeffs(fy, cbuf);
+        else vao_lanczos4_coeffs(fy, cbuf);
         for (int k = 0; k < ksize; k++)
             ibeta[dy * ksize + k] = vao_sat_short(cbuf[k] * 2048);
     }
@@ -1104,7 +1174,7 @@ int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c
         for (int dy = 0; dy < dh; dy++)
             for (int dx = 0; dx < dw; dx++)
                 for (int ch = 0; ch < c; ch++) {
-                    int rows[4];
+                    int rows[8];
                     for (int k = 0; k < ksize; k++) {
                         int sy = yofs[dy] - ksize2 + 1 + k;
                         sy = sy < 0 ? 0 : sy > sh - 1 ? sh - 1 : sy;
@@ -1116,10 +1186,10 @@ int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c
                             else
                                 v = S[xofs[dx] * c + ch] * 2048;
                         } else {
-                            for (int j = 0; j < 4; j++) {
-                                int sxj = xofs[dx] - 1 + j;
+                            for (int j = 0; j < ksize; j++) {
+                                int sxj = xofs[dx] - ksize2 + 1 + j;
                                 sxj = sxj < 0 ? 0 : sxj > sw - 1 ? sw - 1 : sxj;
-                                v += S[sxj * c + ch] * ialpha[dx * 4 + j];
+                                v += S[sxj * c + ch] * ialpha[dx * ksize + j];
                             }
                         }
                         rows[k] = v;
@@ -1128,15 +1198,185 @@ int vao_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c
                     if (mode == 1) {
                         const int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
                         out = (((b0 * (rows[0] >> 4)) >> 16) + ((b1 * (rows[1] >> 4)) >> 16) + 2) >> 2;
-                    } else {
+                    } else if (mode == 2) {
                         long long s = 0;
                         for (int k = 0; k < 4; k++)
                             s += (long long)ibeta[dy * 4 + k] * rows[k];
                         out = (int)((s + (1 << 21)) >> 22);
+                    } else {                    /* LANCZOS4: OpenCV accumulates in int (wraps like its int does) */
+                        uint32_t s = 0;
+                        for (int k = 0; k < 8; k++)
+                            s += (uint32_t)((int)ibeta[dy * 8 + k] * rows[k]);
+                        out = (int)(s + (1u << 21)) >> 22;
                     }
                     dst[f * dfs + ((size_t)dy * dw + dx) * c + ch] = vao_sat_u8i(out);
                 }
     free(xofs); free(yofs); free(ialpha); free(ibeta);
     (void)vao_round_half_even;
+    return 0;
+}
+
+/* cv2.resize on float32 frames (FilterResize takes whatever dtype the video has, video/filters.py:310-314):
+ * the <float, float, float> instantiations of OpenCV's resize templates -- float coefficient tables,
+ * `S[sx]*a0 + S[sx+cn]*a1` / sums of products from the first tap to the last in float, no FMA
+ * contraction, results stored as they are. */
+int vao_resize_f32(const float *src, float *dst, int n, int sh, int sw, int c, int dh, int dw, int mode)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || c <= 0 || mode < 0 || mode > 4)
+        return -1;
+    const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+    const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+    const size_t sfs = (size_t)sh * sw * c, dfs = (size_t)dh * dw * c;
+    if (mode == 0) {
+        const double ifx = 1. / inv_sx, ify = 1. / inv_sy;
+        for (int f = 0; f < n; f++)
+            for (int y = 0; y < dh; y++) {
+                int sy = (int)floor(y * ify);
+                if (sy > sh - 1) sy = sh - 1;
+                for (int x = 0; x < dw; x++) {
+                    int sx = (int)floor(x * ifx);
+                    if (sx > sw - 1) sx = sw - 1;
+                    for (int k = 0; k < c; k++)
+                        dst[f * dfs + ((size_t)y * dw + x) * c + k] = src[f * sfs + ((size_t)sy * sw + sx) * c + k];
+                }
+            }
+        return 0;
+    }
+    int iscale_x = (int)nearbyint(scale_x), iscale_y = (int)nearbyint(scale_y);
+    const int area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    if (mode == 1 && area_fast && iscale_x == 2 && iscale_y == 2)
+        mode = 3;
+    if (mode == 3 && scale_x >= 1 && scale_y >= 1) {
+        if (area_fast) {
+            const float scale = 1.f / (iscale_x * iscale_y);
+            int wfull = (int)(sw / scale_x);
+            if (wfull > dw) wfull = dw;
+            for (int f = 0; f < n; f++)
+                for (int y = 0; y < dh; y++) {
+                    const int sy0 = y * iscale_y;
+                    for (int x = 0; x < dw; x++)
+                        for (int k = 0; k < c; k++) {
+                            const int sx0 = x * iscale_x;
+                            float sum = 0.f;
+                            int count = 0;
+                            for (int yy = 0; yy < iscale_y && sy0 + yy < sh; yy++)
+                                for (int xx = 0; xx < iscale_x && sx0 + xx < sw; xx++) {
+                                    sum += src[f * sfs + ((size_t)(sy0 + yy) * sw + sx0 + xx) * c + k];
+                                    count++;
+                                }
+                            dst[f * dfs + ((size_t)y * dw + x) * c + k] =
+                                (sy0 + iscale_y <= sh && x < wfull) ? sum * scale : sum / count;
+                        }
+                }
+            return 0;
+        }
+        vao_dec_alpha *xt = (vao_dec_alpha *)malloc(sizeof(vao_dec_alpha) * (size_t)(sw * 2 + dw * 2 + 4));
+        vao_dec_alpha *yt = (vao_dec_alpha *)malloc(sizeof(vao_dec_alpha) * (size_t)(sh * 2 + dh * 2 + 4));
+        const int nx = vao_area_tab(sw, dw, scale_x, xt), ny = vao_area_tab(sh, dh, scale_y, yt);
+        float *buf = (float *)malloc(sizeof(float) * (size_t)dw * c), *sum = (float *)malloc(sizeof(float) * (size_t)dw * c);
+        for (int f = 0; f < n; f++) {
+            int prev_dy = yt[0].di;
+            for (int i = 0; i < dw * c; i++) sum[i] = 0.f;
+            for (int j = 0; j < ny; j++) {
+                const float beta = yt[j].alpha;
+                const int dy = yt[j].di, sy = yt[j].si;
+                const float *S = src + f * sfs + (size_t)sy * sw * c;
+                for (int i = 0; i < dw * c; i++) buf[i] = 0.f;
+                for (int k = 0; k < nx; k++)
+                    for (int ch = 0; ch < c; ch++) {
+                        const float p = S[xt[k].si * c + ch] * xt[k].alpha;
+                        buf[xt[k].di * c + ch] += p;
+                    }
+                if (dy != prev_dy) {
+                    float *D = dst + f * dfs + (size_t)prev_dy * dw * c;
+                    for (int i = 0; i < dw * c; i++) {
+                        D[i] = sum[i];
+                        sum[i] = beta * buf[i];
+                    }
+                    prev_dy = dy;
+                } else {
+                    for (int i = 0; i < dw * c; i++) {
+                        const float p = beta * buf[i];
+                        sum[i] += p;
+                    }
+                }
+            }
+            float *D = dst + f * dfs + (size_t)prev_dy * dw * c;
+            for (int i = 0; i < dw * c; i++)
+                D[i] = sum[i];
+        }
+        free(xt); free(yt); free(buf); free(sum);
+        return 0;
+    }
+    const int area_mode = mode == 3;
+    if (area_mode) mode = 1;
+    const int ksize = mode == 1 ? 2 : mode == 2 ? 4 : 8, ksize2 = ksize / 2;
+    int *xofs = (int *)malloc(sizeof(int) * (size_t)dw), *yofs = (int *)malloc(sizeof(int) * (size_t)dh);
+    float *alpha = (float *)malloc(sizeof(float) * (size_t)dw * ksize), *beta = (float *)malloc(sizeof(float) * (size_t)dh * ksize);
+    int xmax = dw;
+    for (int axis = 0; axis < 2; axis++) {
+        const int dsize = axis ? dh : dw, ssize = axis ? sh : sw;
+        const double scale = axis ? scale_y : scale_x, inv = axis ? inv_sy : inv_sx;
+        for (int d = 0; d < dsize; d++) {
+            float fx;
+            int sx;
+            if (!area_mode) {
+                fx = (float)((d + 0.5) * scale - 0.5);
+                sx = (int)floorf(fx);
+                fx -= sx;
+            } else {
+                sx = (int)floor(d * scale);
+                fx = (float)((d + 1) - (sx + 1) * inv);
+                fx = fx <= 0 ? 0.f : fx - floorf(fx);
+            }
+            if (!axis) {
+                if (sx < ksize2 - 1 && sx < 0 && mode == 1) fx = 0, sx = 0;
+                if (sx + ksize2 >= ssize) {
+                    if (d < xmax) xmax = d;
+                    if (sx >= ssize - 1 && mode == 1) fx = 0, sx = ssize - 1;
+                }
+            }
+            (axis ? yofs : xofs)[d] = sx;
+            float *cf = (axis ? beta : alpha) + (size_t)d * ksize;
+            if (mode == 1) cf[0] = 1.f - fx, cf[1] = fx;
+            else if (mode == 2) vao_cubic_coeffs(fx, cf);
+            else vao_lanczos4_coeffs(fx, cf);
+        }
+    }
+    for (int f = 0; f < n; f++)
+        for (int dy = 0; dy < dh; dy++)
+            for (int dx = 0; dx < dw; dx++)
+                for (int ch = 0; ch < c; ch++) {
+                    float rows[8];
+                    for (int k = 0; k < ksize; k++) {
+                        int sy = yofs[dy] - ksize2 + 1 + k;
+                        sy = sy < 0 ? 0 : sy > sh - 1 ? sh - 1 : sy;
+                        const float *S = src + f * sfs + (size_t)sy * sw * c;
+                        float v = 0.f;
+                        if (mode == 1) {
+                            if (dx < xmax) {
+                                const float p0 = S[xofs[dx] * c + ch] * alpha[dx * 2], p1 = S[(xofs[dx] + 1) * c + ch] * alpha[dx * 2 + 1];
+                                v = p0 + p1;
+                            } else {
+                                v = S[xofs[dx] * c + ch] * 1.f;
+                            }
+                        } else {
+                            for (int j = 0; j < ksize; j++) {
+                                int sxj = xofs[dx] - ksize2 + 1 + j;
+                                sxj = sxj < 0 ? 0 : sxj > sw - 1 ? sw - 1 : sxj;
+                                const float p = S[sxj * c + ch] * alpha[dx * ksize + j];
+                                v += p;
+                            }
+                        }
+                        rows[k] = v;
+                    }
+                    float out = rows[0] * beta[dy * ksize];
+                    for (int k = 1; k < ksize; k++) {
+                        const float p = rows[k] * beta[dy * ksize + k];
+                        out += p;
+                    }
+                    dst[f * dfs + ((size_t)dy * dw + dx) * c + ch] = out;
+                }
+    free(xofs); free(yofs); free(alpha); free(beta);
     return 0;
 }

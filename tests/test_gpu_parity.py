@@ -443,6 +443,61 @@ def test_label_4k_frame(ops, oracle):
     assert np.array_equal(cnt, rc) and np.array_equal(lab, rl)
 
 
+# ------------------------------------------------------------------ other dtypes (int16 / float32 inputs)
+@pytest.mark.parametrize("dtype", [np.int16, np.float32, np.uint8])
+def test_temporal_statistics_any_dtype(ops, oracle, dtype):
+    """measure_mean / measure_mean_std on int16 (FilterTimeDifference's output) and float32 videos: the
+    oracle (pinned to literal NumPy in the CPU suite) bit for bit, through ops and through the
+    analysis.video functions on a VideoMemory"""
+    from video.analysis.video import measure_mean, measure_mean_std
+    from video.io.memory import VideoMemory
+    rng = np.random.default_rng(17)
+    if dtype == np.float32:
+        frames = rng.normal(0.4, 0.3, (70, 33, 47)).astype(np.float32)
+    elif dtype == np.int16:
+        frames = rng.integers(-255, 256, (70, 33, 47)).astype(np.int16)
+    else:
+        frames = rng.integers(0, 256, (70, 33, 47)).astype(np.uint8)
+    ref_mean = oracle.mean_any(frames)
+    rm, rq = oracle.welford_any(frames)
+    assert np.array_equal(ops.running_mean(frames), ref_mean)
+    part = ops.running_mean(frames[:29])
+    assert np.array_equal(ops.running_mean(frames[29:], part, 29), ref_mean)
+    gm, gq = ops.welford(frames)
+    assert np.array_equal(gm, rm) and np.array_equal(gq, rq)
+    video = VideoMemory(frames)
+    assert np.array_equal(measure_mean(video), ref_mean)
+    mean, std = measure_mean_std(video)
+    assert np.array_equal(mean, rm) and np.array_equal(std, np.sqrt(rq / (len(frames) - 1)))
+
+
+def test_peaks_and_statistics_on_float_images(ops, oracle):
+    """detect_peaks / get_image_statistics on float32 maps (the reference feeds them distance and
+    correlation maps): comparisons in float, statistics on the truncated values"""
+    from video.analysis.image import detect_peaks, get_image_statistics
+    rng = np.random.default_rng(23)
+    yy, xx = np.mgrid[:90, :130]
+    img = np.zeros((90, 130), np.float32)
+    for cx, cy, s, a in ((20, 30, 6, 3.5), (80, 40, 9, 7.25), (100, 70, 4, -2.0), (5, 85, 5, 4.0)):
+        img += (a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2.0 * s * s))).astype(np.float32)
+    img[img < 1e-3] = 0                                    # exact-zero background with plateaus
+    img[40:44, 60:66] = 2.5                                # a plateau
+    for plateaus in (True, False):
+        assert np.array_equal(detect_peaks(img, plateaus), oracle.detect_peaks(img, plateaus)), plateaus
+        noise = rng.normal(0, 1, (64, 77)).astype(np.float32)
+        assert np.array_equal(detect_peaks(noise, plateaus), oracle.detect_peaks(noise, plateaus))
+    big = (img * 40).astype(np.float32) + rng.uniform(-3, 3, img.shape).astype(np.float32)
+    for kernel, ksize, prior, excl in (("box", 3, 10, False), ("ellipse", 4, 0, True), ("box", 1, 2.5, False)):
+        gm, gv = get_image_statistics(big, kernel, ksize, prior=prior, exclude_center=excl)
+        rm, rv = oracle.image_statistics(big, kernel, ksize, prior, excl)
+        if float(prior).is_integer():
+            assert np.array_equal(gm, rm) and np.array_equal(gv, rv), (kernel, ksize)
+        else:
+            assert np.allclose(gm, rm, rtol=1e-12, atol=1e-12) and np.allclose(gv, rv, rtol=1e-10, atol=1e-9)
+    gm = get_image_statistics(big, "box", 2, ret_var=False)            # prior = image mean
+    assert np.allclose(gm, oracle.image_statistics(big, "box", 2)[0], rtol=1e-12, atol=1e-10)
+
+
 # ------------------------------------------------------------------ stats / largest region
 def test_region_stats_and_moments(ops, oracle, golden):
     for name in [str(n) for n in golden["mask_names"]]:
@@ -1103,7 +1158,7 @@ def test_contracted_chain_runs_one_engine_pass_per_batch_1080p():
     assert passes_fused == [32] * 8 and passes_chain == [32] * 8
 
 
-@pytest.mark.parametrize("mode", ["nearest", "linear", "cubic", "area"])
+@pytest.mark.parametrize("mode", ["nearest", "linear", "cubic", "area", "lanczos"])
 def test_resize_matches_oracle(ops, oracle, mode):
     """N4 FilterResize / cv2.resize restatement: every mode, shrinking and growing, integer and
     fractional factors, 1 and 3 channels, batches -- bit for bit against the oracle"""
@@ -1119,8 +1174,31 @@ def test_resize_matches_oracle(ops, oracle, mode):
     big = rng.integers(0, 256, (1, 1080, 1920), dtype=np.uint8)
     for size in ((960, 540), (640, 360), (1280, 720), (2560, 1440)):
         assert np.array_equal(ops.resize(big, size, mode), oracle.resize_u8(big, size, mode)), (mode, size)
-    flat = np.full((33, 47), 201, np.uint8)                          # unity gain in every mode
-    assert np.array_equal(ops.resize(flat, (80, 21), mode), np.full((21, 80), 201, np.uint8))
+    flat = np.full((33, 47), 201, np.uint8)                          # unity gain (Lanczos: its 8 quantised
+    got = ops.resize(flat, (80, 21), mode)                           # taps need not sum to 2048 exactly)
+    assert np.abs(got.astype(int) - 201).max() <= (1 if mode == "lanczos" else 0)
+    assert np.array_equal(ops.resize(img, (120, 90), mode), img)     # same size: every mode is the identity
+
+
+@pytest.mark.parametrize("mode", ["nearest", "linear", "cubic", "area", "lanczos"])
+def test_resize_f32_matches_oracle(ops, oracle, mode):
+    """FilterResize on float32 frames (the reference resizes whatever dtype the video has,
+    video/filters.py:310-314): the float instantiations of the same algorithms, bit patterns equal
+    to the oracle's (same products, same order of additions, no contraction)"""
+    rng = np.random.default_rng(40 + len(mode))
+    img = rng.normal(0.5, 0.3, (2, 90, 120)).astype(np.float32)
+    col = rng.uniform(-10, 10, (60, 80, 3)).astype(np.float32)
+    img[0, :10] = 1e6
+    for size in ((60, 45), (40, 30), (30, 18), (240, 180), (77, 51), (121, 91), (7, 5), (1, 1), (300, 31)):
+        a, b = ops.resize(img, size, mode), oracle.resize_f32(img, size, mode)
+        assert a.dtype == np.float32 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (mode, size)
+        a, b = ops.resize(col, size, mode, color=True), oracle.resize_f32(col, size, mode, layout="hwc")
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (mode, size, "color")
+    big = rng.uniform(0, 1, (1, 540, 960)).astype(np.float32)
+    for size in ((480, 270), (1280, 720)):
+        assert np.array_equal(ops.resize(big, size, mode).view(np.uint32),
+                              oracle.resize_f32(big, size, mode).view(np.uint32)), (mode, size)
+    assert np.array_equal(ops.resize(img, (120, 90), mode), img)
 
 
 def test_filter_resize_plumbing(ops, oracle):
@@ -1140,8 +1218,12 @@ def test_filter_resize_plumbing(ops, oracle):
     assert np.array_equal(twice[0], oracle.resize_u8(clip[0], (32, 22), "linear"))
     with pytest.raises(ValueError):
         FilterResize(src, 0.5, "bogus")
-    with pytest.raises(NotImplementedError):
-        FilterResize(src, 0.5, "lanczos")
+    lz = FilterResize(src, (135, 90), "lanczos")                     # INTER_LANCZOS4 (reference :293-294)
+    assert np.array_equal(lz[3], oracle.resize_u8(clip[3], (135, 90), "lanczos"))
+    fclip = clip.astype(np.float32) / 255
+    fl = FilterResize(VideoMemory(fclip), 0.5)                       # float32 videos resize as float32
+    got = np.stack(list(fl))
+    assert got.dtype == np.float32 and np.array_equal(got, oracle.resize_f32(fclip, (45, 30), "area"))
 
 
 def _philox_normals(seed, first_index, count):

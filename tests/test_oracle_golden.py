@@ -352,3 +352,66 @@ def test_cv3_taps_and_blur(oracle, sigma):
     acc = sum(int(taps[j]) * pad[j:j + im.shape[0], :] for j in range(len(taps)))
     ref = np.minimum((acc + 32768) >> 16, 255).astype(np.uint8)
     assert np.array_equal(oracle.gaussian_u8(im, sigma, tap_rule="cv3"), ref)
+
+
+# ---------------------------------------------------------------------------- Lanczos-4 / float32 resize
+def test_lanczos4_and_float_resize_known_answers(oracle):
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (31, 45), dtype=np.uint8)
+    fimg = rng.normal(0, 1, (31, 45)).astype(np.float32)
+    for mode in ("nearest", "linear", "cubic", "area", "lanczos"):
+        # same size: sample positions fall on the pixels, every kernel degenerates to a delta
+        assert np.array_equal(oracle.resize_u8(img, (45, 31), mode), img), mode
+        assert np.array_equal(oracle.resize_f32(fimg, (45, 31), mode), fimg), mode
+        # constant images stay constant (float: to rounding; Lanczos u8: its quantised taps, +-1)
+        flat = oracle.resize_u8(np.full((20, 30), 77, np.uint8), (47, 33), mode)
+        assert np.abs(flat.astype(int) - 77).max() <= (1 if mode == "lanczos" else 0), mode
+        fflat = oracle.resize_f32(np.full((20, 30), 0.25, np.float32), (47, 33), mode)
+        assert np.abs(fflat - 0.25).max() < 1e-6, mode
+    # float32 linear, growing 2x along x only: literal two-tap formula with OpenCV's sample positions
+    row = np.arange(8, dtype=np.float32)[None, :] ** 2
+    out = oracle.resize_f32(np.repeat(row, 3, 0), (16, 3), "linear")
+    fx = ((np.arange(16) + 0.5) * 0.5 - 0.5).astype(np.float32)
+    sx = np.floor(fx).astype(int)
+    a1 = (fx - sx).astype(np.float32)
+    left, right = np.clip(sx, 0, 7), np.clip(sx + 1, 0, 7)
+    a1 = np.where(sx < 0, 0, np.where(sx >= 7, 0, a1)).astype(np.float32)
+    expect = row[0, left] * (np.float32(1) - a1) + row[0, right] * a1
+    assert np.allclose(out[1], expect, rtol=0, atol=1e-5)
+    # Lanczos shrinks a smooth ramp to (nearly) a ramp and overshoots at a step (negative lobes)
+    ramp = np.tile(np.linspace(20, 220, 64).astype(np.float32), (8, 1))
+    small = oracle.resize_f32(ramp, (32, 8), "lanczos")
+    assert np.abs(np.diff(small[4, 4:-4]) - (200 / 63 * 2)).max() < 0.05
+    step = np.zeros((8, 64), np.float32)
+    step[:, 32:] = 1
+    big = oracle.resize_f32(step, (128, 8), "lanczos")
+    assert big.max() > 1.02 and big.min() < -0.02
+
+
+# ---------------------------------------------------------------------------- temporal statistics, any dtype
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32])
+def test_temporal_statistics_follow_numpy_promotions(oracle, dtype):
+    """measure_mean / measure_mean_std (video/analysis/video.py:26-55) executed LITERALLY with NumPy on
+    frames of the dtypes the reference meets; the oracle restates the promotions (float32 frames:
+    `frame/(n + 1)` is a float32 quotient) and must reproduce every bit"""
+    rng = np.random.default_rng(7)
+    if dtype == np.float32:
+        frames = rng.normal(0.4, 0.3, (11, 9, 13)).astype(np.float32)
+    elif dtype == np.int16:
+        frames = rng.integers(-255, 256, (11, 9, 13)).astype(np.int16)
+    else:
+        frames = rng.integers(0, 256, (11, 9, 13)).astype(np.uint8)
+    mean = np.zeros(frames.shape[1:])
+    for n, frame in enumerate(frames):                       # video/analysis/video.py:32-33
+        mean = mean * n / (n + 1) + frame / (n + 1)
+    assert np.array_equal(oracle.mean_any(frames), mean)
+    m, M2 = np.zeros(frames.shape[1:]), np.zeros(frames.shape[1:])
+    for n, frame in enumerate(frames):                       # :47-50
+        delta = frame - m
+        m = m + delta / (n + 1)
+        M2 = M2 + delta * (frame - m)
+    om, oq = oracle.welford_any(frames)
+    assert np.array_equal(om, m) and np.array_equal(oq, M2)
+    # split batches continue the recurrence
+    a = oracle.mean_any(frames[:4])
+    assert np.array_equal(oracle.mean_any(frames[4:], a, 4), mean)

@@ -121,6 +121,32 @@ struct va_pipeline {
     StageProfiler *prof;
 };
 
+// cv2.resize entry points (uint8 / float32 share everything but the kernels)
+template <class T>
+static int resize_any(const T *src, T *dst, int n, int src_h, int src_w, int c, int dst_h, int dst_w,
+                      int interpolation, void *stream, const char *who)
+{
+    VA_ENTER();
+    VA_REQUIRE(src && dst && src != dst, "%s: src/dst must be distinct non-NULL", who);
+    VA_REQUIRE(n >= 0 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0 && c >= 1 && c <= 4,
+               "%s: bad shape (%d,%d,%d,%d) -> (%d,%d)", who, n, src_h, src_w, c, dst_h, dst_w);
+    VA_REQUIRE((size_t)src_h * src_w < kMaxFramePixels && (size_t)dst_h * dst_w < kMaxFramePixels,
+               "%s: frames above 2^29 pixels are not supported", who);
+    VA_REQUIRE(interpolation >= VA_INTER_NEAREST && interpolation <= VA_INTER_LANCZOS4,
+               "%s: interpolation %d not supported (0 nearest, 1 linear, 2 cubic, 3 area, 4 lanczos4)", who,
+               interpolation);
+    ScratchLease scratch;
+    int rc = scratch.acquire(resize_scratch_bytes(src_h, src_w, dst_h, dst_w), as_stream(stream));
+    if (rc)
+        return rc;
+    if constexpr (sizeof(T) == 1)
+        return launch_resize_u8(src, dst, n, src_h, src_w, c, dst_h, dst_w, interpolation, scratch.ptr,
+                                as_stream(stream));
+    else
+        return launch_resize_f32(src, dst, n, src_h, src_w, c, dst_h, dst_w, interpolation, scratch.ptr,
+                                 as_stream(stream));
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------------------ runtime
@@ -508,6 +534,19 @@ int va_welford_u8(const uint8_t *frames, double *mean, double *m2, int64_t n_see
     return launch_welford(frames, mean, m2, n_seen, n, px, as_stream(stream));
 }
 
+int va_mean_any(const void *frames, int dtype, double *mean, int64_t n_seen, int n, size_t px, void *stream)
+{
+    VA_ENTER();
+    return launch_temporal_stats(frames, dtype, mean, nullptr, n_seen, n, px, as_stream(stream));
+}
+int va_welford_any(const void *frames, int dtype, double *mean, double *m2, int64_t n_seen, int n, size_t px,
+                   void *stream)
+{
+    VA_ENTER();
+    VA_REQUIRE(m2, "va_welford_any: NULL argument");
+    return launch_temporal_stats(frames, dtype, mean, m2, n_seen, n, px, as_stream(stream));
+}
+
 // ------------------------------------------------------------------------------ pointwise
 int va_time_difference_u8(const uint8_t *a, const uint8_t *b, int16_t *out, size_t count,
                           void *stream)
@@ -674,6 +713,33 @@ int va_detect_peaks_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, in
     return launch_detect_peaks(src, dst, n, h, w, include_plateaus, as_stream(stream));
 }
 
+int va_detect_peaks_f32(const float *src, uint8_t *dst, int n, int h, int w, int include_plateaus, void *stream)
+{
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_detect_peaks_f32: frames above 2^29 pixels are not supported");
+    VA_REQUIRE(src && dst && (const void *)src != (const void *)dst, "va_detect_peaks_f32: bad pointers");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0, "va_detect_peaks_f32: bad shape");
+    return launch_detect_peaks_f32(src, dst, n, h, w, include_plateaus, as_stream(stream));
+}
+
+int va_image_statistics_f32(const float *src, double *mean_out, double *var_out, int n, int h, int w, int kernel,
+                            int ksize, double prior, int exclude_center, void *stream)
+{
+    VA_ENTER();
+    VA_REQUIRE(h <= 0 || w <= 0 || (size_t)h * (size_t)w < kMaxFramePixels,
+               "va_image_statistics_f32: frames above 2^29 pixels are not supported");
+    VA_REQUIRE(src && mean_out, "va_image_statistics_f32: NULL argument");
+    VA_REQUIRE(n >= 0 && h > 0 && w > 0 && ksize >= 0, "va_image_statistics_f32: bad shape");
+    VA_REQUIRE(kernel == 0 || kernel == 1, "va_image_statistics_f32: kernel must be 0 (box) or 1 (ellipse)");
+    RowSpans se;
+    int rc = make_row_spans(kernel == 0 ? VA_SHAPE_RECT : VA_SHAPE_ELLIPSE, 2 * ksize + 1, &se);
+    if (rc)
+        return rc;
+    return launch_image_statistics_f32(src, mean_out, var_out, n, h, w, se, prior, exclude_center,
+                                       as_stream(stream));
+}
+
 int va_mask_thinning_u8(uint8_t *img, uint8_t *scratch, uint8_t *skel, int h, int w,
                         int *iterations_out, void *stream)
 {
@@ -793,20 +859,13 @@ int va_largest_contour(const uint8_t *mask, int n, int h, int w, int32_t *points
 int va_resize_u8(const uint8_t *src, uint8_t *dst, int n, int src_h, int src_w, int c, int dst_h, int dst_w,
                  int interpolation, void *stream)
 {
-    VA_ENTER();
-    VA_REQUIRE(src && dst && src != dst, "va_resize_u8: src/dst must be distinct non-NULL");
-    VA_REQUIRE(n >= 0 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0 && c >= 1 && c <= 4,
-               "va_resize_u8: bad shape (%d,%d,%d,%d) -> (%d,%d)", n, src_h, src_w, c, dst_h, dst_w);
-    VA_REQUIRE((size_t)src_h * src_w < kMaxFramePixels && (size_t)dst_h * dst_w < kMaxFramePixels,
-               "va_resize_u8: frames above 2^29 pixels are not supported");
-    VA_REQUIRE(interpolation >= VA_INTER_NEAREST && interpolation <= VA_INTER_AREA,
-               "va_resize_u8: interpolation %d not supported (0 nearest, 1 linear, 2 cubic, 3 area)", interpolation);
-    ScratchLease scratch;
-    int rc = scratch.acquire(resize_scratch_bytes(src_h, src_w, dst_h, dst_w), as_stream(stream));
-    if (rc)
-        return rc;
-    return launch_resize_u8(src, dst, n, src_h, src_w, c, dst_h, dst_w, interpolation, scratch.ptr,
-                            as_stream(stream));
+    return resize_any<uint8_t>(src, dst, n, src_h, src_w, c, dst_h, dst_w, interpolation, stream, "va_resize_u8");
+}
+
+int va_resize_f32(const float *src, float *dst, int n, int src_h, int src_w, int c, int dst_h, int dst_w,
+                  int interpolation, void *stream)
+{
+    return resize_any<float>(src, dst, n, src_h, src_w, c, dst_h, dst_w, interpolation, stream, "va_resize_f32");
 }
 
 int va_contour_moments(const void *points, const int32_t *npoints, int n, int max_points,

@@ -144,6 +144,9 @@ int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, 
 int launch_welford(const uint8_t *frames, double *mean, double *m2, int64_t n_seen, int n,
                    size_t px, hipStream_t st);
 
+// running mean (m2 == nullptr) or Welford mean + M2 over frames of dtype VA_U8 / VA_I16 / VA_F32
+int launch_temporal_stats(const void *frames, int dtype, double *mean, double *m2, int64_t n_seen, int n,
+                          size_t px, hipStream_t st);
 int launch_threshold_u8(const uint8_t *src, uint8_t *dst, size_t count, int thresh, int maxval,
                         hipStream_t st);
 int launch_time_difference(const uint8_t *a, const uint8_t *b, int16_t *out, size_t count,
@@ -181,6 +184,10 @@ int launch_morph_bits(const uint32_t *src, uint32_t *dst, int n, int h, int w, i
 // small stencils (va_stencil.hip)
 int launch_detect_peaks(const uint8_t *src, uint8_t *dst, int n, int h, int w, int include_plateaus,
                         hipStream_t st);
+int launch_detect_peaks_f32(const float *src, uint8_t *dst, int n, int h, int w, int include_plateaus,
+                            hipStream_t st);
+int launch_image_statistics_f32(const float *src, double *mean_out, double *var_out, int n, int h, int w,
+                                const RowSpans &se, double prior, int exclude_center, hipStream_t st);
 int launch_thinning_step(const uint8_t *img, uint8_t *eroded, uint8_t *skel, int n, int h, int w,
                          unsigned long long *nonzero, hipStream_t st);
 size_t image_statistics_scratch_bytes(int n, int h, int w);
@@ -235,10 +242,12 @@ int launch_prepare_u8(const uint8_t *src, uint8_t *dst, int n, int src_h, int sr
                       double tmin, hipStream_t st);
 int launch_gaussian_noise(void *dst, int dtype, size_t count, double mean, double stdev, uint64_t seed,
                           uint64_t first_index, hipStream_t st);
-// cv2.resize for uint8 frames (va_resize.hip); mode 0 nearest, 1 linear, 2 cubic, 3 area
+// cv2.resize for uint8 / float32 frames (va_resize.hip); mode 0 nearest, 1 linear, 2 cubic, 3 area, 4 lanczos4
 size_t resize_scratch_bytes(int sh, int sw, int dh, int dw);
 int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,
                      void *scratch, hipStream_t st);
+int launch_resize_f32(const float *src, float *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,
+                      void *scratch, hipStream_t st);
 // cv2.moments(contour): ten spatial moments (float64) per contour, points int32 or float32 (x, y)
 int launch_contour_moments(const void *points, const int32_t *npoints, int n, int max_points,
                            int is_float, double *out, hipStream_t st);

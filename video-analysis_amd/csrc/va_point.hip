@@ -340,6 +340,48 @@ welford_u8_kernel(const uint8_t *__restrict__ frames, double *__restrict__ mean,
     }
 }
 
+// ---- measure_mean / measure_mean_std on frames of any dtype the reference meets (uint8 from the
+//      codecs, int16 from FilterTimeDifference, float32 from normalised videos), video/analysis/video.py:26-55.
+// NumPy's promotions are part of the definition: `frame/(n + 1)` is float64 for integer frames but
+// FLOAT32 for float32 frames (a float32 array divided by a Python int stays float32), and only then
+// joins the float64 running mean; Welford's `frame - mean` promotes the frame exactly.
+template <class T>
+__device__ __forceinline__ double quotient_as_numpy(T v, double dn1)
+{
+    return (double)v / dn1;
+}
+template <>
+__device__ __forceinline__ double quotient_as_numpy<float>(float v, double dn1)
+{
+    // float32 / float32(n + 1), correctly rounded (the double quotient rounds to the same float: 53 >= 2*24 + 2)
+    return (double)(float)((double)v / (double)(float)dn1);
+}
+
+template <class T, bool WELFORD>
+__global__ void __launch_bounds__(kBlock)
+temporal_stats_kernel(const T *__restrict__ frames, double *__restrict__ mean, double *__restrict__ m2,
+                      long long n_seen, int n, size_t px)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= px)
+        return;
+    double m = mean[i], q = WELFORD ? m2[i] : 0.0;
+    for (int f = 0; f < n; f++) {
+        const T v = frames[(size_t)f * px + i];
+        const double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
+        if (WELFORD) {
+            const double fr = (double)v, delta = fr - m;
+            m = m + delta / dn1;
+            q = q + delta * (fr - m);
+        } else {
+            m = m * dn / dn1 + quotient_as_numpy<T>(v, dn1);
+        }
+    }
+    mean[i] = m;
+    if (WELFORD)
+        m2[i] = q;
+}
+
 // ---- pointwise ------------------------------------------------------------------------------
 // 16 bytes per lane where the buffers allow it, scalar tail otherwise
 __global__ void __launch_bounds__(kBlock)
@@ -511,6 +553,33 @@ int launch_welford(const uint8_t *frames, double *mean, double *m2, int64_t n_se
     else
         welford_u8_kernel<1><<<grid, kBlock, 0, st>>>(frames, mean, m2, n_seen, n, px);
     VA_LAUNCH_CHECK("welford_u8_kernel");
+    return VA_OK;
+}
+
+int launch_temporal_stats(const void *frames, int dtype, double *mean, double *m2, int64_t n_seen, int n,
+                          size_t px, hipStream_t st)
+{
+    VA_REQUIRE(frames && mean, "temporal statistics: NULL argument");
+    VA_REQUIRE(dtype == VA_U8 || dtype == VA_I16 || dtype == VA_F32,
+               "temporal statistics: frames must be uint8, int16 or float32 (dtype code %d)", dtype);
+    if (n <= 0 || px == 0)
+        return VA_OK;
+    const int grid = cdiv((long long)px, kBlock);
+#define VA_TS(T)                                                                                            \
+    do {                                                                                                    \
+        if (m2)                                                                                             \
+            temporal_stats_kernel<T, true><<<grid, kBlock, 0, st>>>((const T *)frames, mean, m2, n_seen, n, px);  \
+        else                                                                                                \
+            temporal_stats_kernel<T, false><<<grid, kBlock, 0, st>>>((const T *)frames, mean, m2, n_seen, n, px); \
+    } while (0)
+    if (dtype == VA_U8)
+        VA_TS(uint8_t);
+    else if (dtype == VA_I16)
+        VA_TS(int16_t);
+    else
+        VA_TS(float);
+#undef VA_TS
+    VA_LAUNCH_CHECK("temporal_stats_kernel");
     return VA_OK;
 }
 

@@ -13,6 +13,9 @@
 //   mode 3 AREA: integer shrink factors = block means, other shrinks = cell-overlap weights in
 //          float (summation order of OpenCV's ResizeArea_Invoker), growing = LINEAR with
 //          area-style sample positions
+//   mode 4 LANCZOS4: 8 x 8 taps, 11-bit fixed point like CUBIC, int32 accumulation
+// float32 frames (launch_resize_f32): the same tables with float coefficients, products summed
+// from the first tap to the last in float (no contraction), no rounding step at the end.
 // Parity with real OpenCV is unpinned offline (no cv2); the oracle restates the same published
 // algorithm independently in C (the test-side CPU restatement) and the two are compared bit
 // for bit by the GPU parity tests.
@@ -29,8 +32,9 @@ constexpr int kBlock = 256;
 
 __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-resize_nn_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int *__restrict__ xofs,
+resize_nn_kernel(const T *__restrict__ src, T *__restrict__ dst, const int *__restrict__ xofs,
                  const int *__restrict__ yofs, int sh, int sw, int c, int dh, int dw, size_t total)
 {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -73,10 +77,10 @@ resize_taps_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, c
                 v = S[(size_t)sx * c] * 2048;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int sxj = sx - 1 + j;
+            for (int j = 0; j < KS; j++) {
+                int sxj = sx - KS / 2 + 1 + j;
                 sxj = sxj < 0 ? 0 : (sxj > sw - 1 ? sw - 1 : sxj);     // replicated border
-                v += S[(size_t)sxj * c] * ialpha[dx * 4 + j];
+                v += S[(size_t)sxj * c] * ialpha[dx * KS + j];
             }
         }
         rows[k] = v;
@@ -85,14 +89,89 @@ resize_taps_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, c
     if (KS == 2) {
         const int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
         out = (((b0 * (rows[0] >> 4)) >> 16) + ((b1 * (rows[1] >> 4)) >> 16) + 2) >> 2;
-    } else {
+    } else if (KS == 4) {
         long long s = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++)
             s += (long long)ibeta[dy * 4 + k] * rows[k];
         out = (int)((s + (1 << 21)) >> 22);
+    } else {                                    // LANCZOS4: OpenCV accumulates in int (and wraps like it)
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < KS; k++)
+            s += (uint32_t)((int)ibeta[dy * KS + k] * rows[k]);
+        out = (int)(s + (1u << 21)) >> 22;
     }
     dst[i] = sat_u8(out);
+}
+
+// float32 frames: float coefficients, left-to-right sums of products (-ffp-contract=off: no FMA)
+template <int KS>
+__global__ void __launch_bounds__(kBlock)
+resize_taps_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, const int *__restrict__ xofs,
+                       const float *__restrict__ alpha, const int *__restrict__ yofs,
+                       const float *__restrict__ beta, int xmax, int sh, int sw, int c, int dh, int dw,
+                       size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total)
+        return;
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
+    const size_t f = p / ((size_t)dw * dh);
+    const float *frame = src + f * (size_t)sh * sw * c;
+    const int sx = xofs[dx];
+    float out = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; k++) {
+        int sy = yofs[dy] - KS / 2 + 1 + k;
+        sy = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        const float *S = frame + (size_t)sy * sw * c + ch;
+        float v = 0.f;
+        if (KS == 2) {
+            if (dx < xmax) {
+                const float p0 = S[(size_t)sx * c] * alpha[dx * 2], p1 = S[(size_t)(sx + 1) * c] * alpha[dx * 2 + 1];
+                v = p0 + p1;
+            } else {
+                v = S[(size_t)sx * c] * 1.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KS; j++) {
+                int sxj = sx - KS / 2 + 1 + j;
+                sxj = sxj < 0 ? 0 : (sxj > sw - 1 ? sw - 1 : sxj);
+                const float pr = S[(size_t)sxj * c] * alpha[dx * KS + j];
+                v += pr;
+            }
+        }
+        const float pr = v * beta[dy * KS + k];
+        out = k == 0 ? pr : out + pr;
+    }
+    dst[i] = out;
+}
+
+__global__ void __launch_bounds__(kBlock)
+resize_area_fast_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, int isx, int isy,
+                            int wfull, int sh, int sw, int c, int dh, int dw, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total)
+        return;
+    const int ch = (int)(i % c);
+    const size_t p = i / c;
+    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
+    const size_t f = p / ((size_t)dw * dh);
+    const float *frame = src + f * (size_t)sh * sw * c + ch;
+    const int sx0 = dx * isx, sy0 = dy * isy;
+    float sum = 0.f;
+    int count = 0;
+    for (int yy = 0; yy < isy && sy0 + yy < sh; yy++)
+        for (int xx = 0; xx < isx && sx0 + xx < sw; xx++) {
+            sum += frame[((size_t)(sy0 + yy) * sw + sx0 + xx) * c];
+            count++;
+        }
+    dst[i] = (sy0 + isy <= sh && dx < wfull) ? sum * (1.f / (float)(isx * isy)) : sum / (float)count;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -131,8 +210,12 @@ struct DecAlpha {
     float alpha;
 };
 
+__device__ __forceinline__ void store_area(uint8_t *p, float v) { *p = sat_u8(__float2int_rn(v)); }
+__device__ __forceinline__ void store_area(float *p, float v) { *p = v; }
+
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-resize_area_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const DecAlpha *__restrict__ xtab,
+resize_area_kernel(const T *__restrict__ src, T *__restrict__ dst, const DecAlpha *__restrict__ xtab,
                    const int *__restrict__ xstart, const DecAlpha *__restrict__ ytab,
                    const int *__restrict__ ystart, int sh, int sw, int c, int dh, int dw, size_t total)
 {
@@ -143,11 +226,11 @@ resize_area_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, c
     const size_t p = i / c;
     const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
     const size_t f = p / ((size_t)dw * dh);
-    const uint8_t *frame = src + f * (size_t)sh * sw * c + ch;
+    const T *frame = src + f * (size_t)sh * sw * c + ch;
     float sum = 0.f;
     bool firstrow = true;
     for (int j = ystart[dy]; j < ystart[dy + 1]; j++) {
-        const uint8_t *S = frame + (size_t)ytab[j].si * sw * c;
+        const T *S = frame + (size_t)ytab[j].si * sw * c;
         float buf = 0.f;
         for (int k = xstart[dx]; k < xstart[dx + 1]; k++) {
             const float prod = (float)S[(size_t)xtab[k].si * c] * xtab[k].alpha;
@@ -157,7 +240,7 @@ resize_area_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, c
         sum = firstrow ? t : sum + t;
         firstrow = false;
     }
-    dst[i] = sat_u8(__float2int_rn(sum));
+    store_area(dst + i, sum);
 }
 
 short sat_short(float v)
@@ -173,6 +256,29 @@ void cubic_coeffs(float x, float *cf)
     cf[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
     cf[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
     cf[3] = 1.f - cf[0] - cf[1] - cf[2];
+}
+
+void lanczos4_coeffs(float x, float *coeffs)          // OpenCV's interpolateLanczos4
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    if (x < 1.1920928955078125e-07f) {
+        for (int i = 0; i < 8; i++)
+            coeffs[i] = 0;
+        coeffs[3] = 1;
+        return;
+    }
+    float sum = 0;
+    const double pi = 3.1415926535897932384626433832795;
+    const double y0 = -(double)(x + 3) * pi * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const double y = -(double)(x + 3 - i) * pi * 0.25;
+        coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += coeffs[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++)
+        coeffs[i] *= sum;
 }
 
 void area_tab(int ssize, int dsize, double scale, std::vector<DecAlpha> &tab, std::vector<int> &start)
@@ -197,14 +303,16 @@ void area_tab(int ssize, int dsize, double scale, std::vector<DecAlpha> &tab, st
 
 // index / weight tables of the LINEAR and CUBIC paths along one axis
 void taps_tab(int ssize, int dsize, int ksize, bool area_mode, bool clamp_linear, std::vector<int> &ofs,
-              std::vector<short> &coef, int *xmax_out)
+              std::vector<short> &coef, int *xmax_out, std::vector<float> *fcoef = nullptr)
 {
     const double inv = (double)dsize / ssize, scale = 1. / inv;
     const int ksize2 = ksize / 2;
     ofs.resize(dsize);
     coef.resize((size_t)dsize * ksize);
+    if (fcoef)
+        fcoef->resize((size_t)dsize * ksize);
     int xmax = dsize;
-    float cbuf[4];
+    float cbuf[8];
     for (int d = 0; d < dsize; d++) {
         float fx;
         int sx;
@@ -229,10 +337,15 @@ void taps_tab(int ssize, int dsize, int ksize, bool area_mode, bool clamp_linear
         ofs[d] = sx;
         if (ksize == 2)
             cbuf[0] = 1.f - fx, cbuf[1] = fx;
-        else
+        else if (ksize == 4)
             cubic_coeffs(fx, cbuf);
-        for (int k = 0; k < ksize; k++)
+        else
+            lanczos4_coeffs(fx, cbuf);
+        for (int k = 0; k < ksize; k++) {
             coef[(size_t)d * ksize + k] = sat_short(cbuf[k] * 2048);
+            if (fcoef)
+                (*fcoef)[(size_t)d * ksize + k] = cbuf[k];
+        }
     }
     if (xmax_out)
         *xmax_out = xmax;
@@ -244,17 +357,19 @@ void taps_tab(int ssize, int dsize, int ksize, bool area_mode, bool clamp_linear
 size_t resize_scratch_bytes(int sh, int sw, int dh, int dw)
 {
     const size_t ints = (size_t)dw + dh + 4 + (size_t)dw + dh + 4;
-    const size_t shorts = 4 * ((size_t)dw + dh);
+    const size_t shorts = 16 * ((size_t)dw + dh);        // (up to 8 taps; float tables for float32 frames)
     const size_t tabs = 2 * ((size_t)sw + sh) + 2 * ((size_t)dw + dh) + 8;
     return ints * 4 + shorts * 2 + tabs * sizeof(DecAlpha) + 1024;
 }
 
-int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,
-                     void *scratch, hipStream_t st)
+template <class T>
+static int launch_resize(const T *src, T *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,
+                         void *scratch, hipStream_t st)
 {
+    constexpr bool F32 = sizeof(T) == 4;
     VA_REQUIRE(src && dst && scratch, "resize: NULL argument");
     VA_REQUIRE(n >= 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && c > 0 && c <= 4, "resize: bad shape");
-    VA_REQUIRE(mode >= 0 && mode <= 3, "resize: interpolation must be 0 nearest, 1 linear, 2 cubic or 3 area");
+    VA_REQUIRE(mode >= 0 && mode <= 4, "resize: interpolation must be 0 nearest, 1 linear, 2 cubic, 3 area or 4 lanczos4");
     const size_t total = (size_t)n * dh * dw * c;
     if (total == 0)
         return VA_OK;
@@ -286,7 +401,7 @@ int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, in
         void *dx, *dy;
         if ((rc = push(xo.data(), xo.size() * 4, &dx)) || (rc = push(yo.data(), yo.size() * 4, &dy)))
             return rc;
-        resize_nn_kernel<<<grid, kBlock, 0, st>>>(src, dst, (const int *)dx, (const int *)dy, sh, sw, c, dh, dw, total);
+        resize_nn_kernel<T><<<grid, kBlock, 0, st>>>(src, dst, (const int *)dx, (const int *)dy, sh, sw, c, dh, dw, total);
         VA_LAUNCH_CHECK("resize_nn_kernel");
         return VA_OK;
     }
@@ -299,8 +414,12 @@ int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, in
         if (area_fast) {
             int wfull = (int)(sw / scale_x);
             wfull = wfull < dw ? wfull : dw;
-            resize_area_fast_kernel<<<grid, kBlock, 0, st>>>(src, dst, iscale_x, iscale_y, wfull, sh, sw, c, dh,
-                                                            dw, total);
+            if constexpr (F32)
+                resize_area_fast_f32_kernel<<<grid, kBlock, 0, st>>>(src, dst, iscale_x, iscale_y, wfull, sh, sw, c, dh,
+                                                                    dw, total);
+            else
+                resize_area_fast_kernel<<<grid, kBlock, 0, st>>>(src, dst, iscale_x, iscale_y, wfull, sh, sw, c, dh,
+                                                                dw, total);
             VA_LAUNCH_CHECK("resize_area_fast_kernel");
             return VA_OK;
         }
@@ -312,30 +431,63 @@ int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, in
         if ((rc = push(xt.data(), xt.size() * sizeof(DecAlpha), &dxt)) || (rc = push(xs.data(), xs.size() * 4, &dxs)) ||
             (rc = push(yt.data(), yt.size() * sizeof(DecAlpha), &dyt)) || (rc = push(ys.data(), ys.size() * 4, &dys)))
             return rc;
-        resize_area_kernel<<<grid, kBlock, 0, st>>>(src, dst, (const DecAlpha *)dxt, (const int *)dxs,
-                                                   (const DecAlpha *)dyt, (const int *)dys, sh, sw, c, dh, dw, total);
+        resize_area_kernel<T><<<grid, kBlock, 0, st>>>(src, dst, (const DecAlpha *)dxt, (const int *)dxs,
+                                                      (const DecAlpha *)dyt, (const int *)dys, sh, sw, c, dh, dw, total);
         VA_LAUNCH_CHECK("resize_area_kernel");
         return VA_OK;
     }
     const bool area_mode = mode == 3;
-    const int ksize = (mode == 2) ? 4 : 2;
+    const int ksize = mode == 2 ? 4 : (mode == 4 ? 8 : 2);
     std::vector<int> xo, yo;
     std::vector<short> ia, ib;
+    std::vector<float> fa, fb;
     int xmax = dw;
-    taps_tab(sw, dw, ksize, area_mode, true, xo, ia, &xmax);
-    taps_tab(sh, dh, ksize, area_mode, false, yo, ib, nullptr);
+    taps_tab(sw, dw, ksize, area_mode, true, xo, ia, &xmax, &fa);
+    taps_tab(sh, dh, ksize, area_mode, false, yo, ib, nullptr, &fb);
     void *dxo, *dia, *dyo, *dib;
-    if ((rc = push(xo.data(), xo.size() * 4, &dxo)) || (rc = push(ia.data(), ia.size() * 2, &dia)) ||
-        (rc = push(yo.data(), yo.size() * 4, &dyo)) || (rc = push(ib.data(), ib.size() * 2, &dib)))
+    if ((rc = push(xo.data(), xo.size() * 4, &dxo)) || (rc = push(yo.data(), yo.size() * 4, &dyo)))
         return rc;
-    if (ksize == 2)
-        resize_taps_kernel<2><<<grid, kBlock, 0, st>>>(src, dst, (const int *)dxo, (const short *)dia, (const int *)dyo,
-                                                      (const short *)dib, xmax, sh, sw, c, dh, dw, total);
-    else
-        resize_taps_kernel<4><<<grid, kBlock, 0, st>>>(src, dst, (const int *)dxo, (const short *)dia, (const int *)dyo,
-                                                      (const short *)dib, xmax, sh, sw, c, dh, dw, total);
+    if constexpr (F32) {
+        if ((rc = push(fa.data(), fa.size() * 4, &dia)) || (rc = push(fb.data(), fb.size() * 4, &dib)))
+            return rc;
+#define VA_F32_TAPS(KS)                                                                                              \
+    resize_taps_f32_kernel<KS><<<grid, kBlock, 0, st>>>(src, dst, (const int *)dxo, (const float *)dia, (const int *)dyo, \
+                                                       (const float *)dib, xmax, sh, sw, c, dh, dw, total)
+        if (ksize == 2)
+            VA_F32_TAPS(2);
+        else if (ksize == 4)
+            VA_F32_TAPS(4);
+        else
+            VA_F32_TAPS(8);
+#undef VA_F32_TAPS
+    } else {
+        if ((rc = push(ia.data(), ia.size() * 2, &dia)) || (rc = push(ib.data(), ib.size() * 2, &dib)))
+            return rc;
+#define VA_U8_TAPS(KS)                                                                                               \
+    resize_taps_kernel<KS><<<grid, kBlock, 0, st>>>(src, dst, (const int *)dxo, (const short *)dia, (const int *)dyo,   \
+                                                   (const short *)dib, xmax, sh, sw, c, dh, dw, total)
+        if (ksize == 2)
+            VA_U8_TAPS(2);
+        else if (ksize == 4)
+            VA_U8_TAPS(4);
+        else
+            VA_U8_TAPS(8);
+#undef VA_U8_TAPS
+    }
     VA_LAUNCH_CHECK("resize_taps_kernel");
     return VA_OK;
+}
+
+int launch_resize_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,
+                     void *scratch, hipStream_t st)
+{
+    return launch_resize<uint8_t>(src, dst, n, sh, sw, c, dh, dw, mode, scratch, st);
+}
+
+int launch_resize_f32(const float *src, float *dst, int n, int sh, int sw, int c, int dh, int dw, int mode,
+                      void *scratch, hipStream_t st)
+{
+    return launch_resize<float>(src, dst, n, sh, sw, c, dh, dw, mode, scratch, st);
 }
 
 }  // namespace va

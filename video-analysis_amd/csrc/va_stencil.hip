@@ -18,8 +18,11 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // detect_peaks: include_plateaus -> (img == max over the 3x3 window) XOR (whole 3x3 window is
 // background, pixels outside the frame counting as background); else img > max over the 8
 // neighbours
+// (T = uint8_t or float: the reference feeds it float maps as well; the maximum starts from the centre
+//  pixel, so negative values are handled)
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-detect_peaks_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w,
+detect_peaks_kernel(const T *__restrict__ src, uint8_t *__restrict__ dst, int h, int w,
                     size_t total, int include_plateaus)
 {
     size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -28,21 +31,25 @@ detect_peaks_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, 
     const int x = (int)(e % w);
     const size_t rowi = e / w;
     const int y = (int)(rowi % h);
-    const uint8_t *frame = src + (rowi - y) * (size_t)w;
-    const int c = frame[(size_t)y * w + x];
-    int mx_all = 0, mx_nb = 0, any_fg = 0;
+    const T *frame = src + (rowi - y) * (size_t)w;
+    const T c = frame[(size_t)y * w + x];
+    T mx_all = c, mx_nb = c;
+    bool nb_set = false;
+    int any_fg = 0;
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
         for (int dx = -1; dx <= 1; dx++) {
             const int yy = clampi(y + dy, 0, h - 1), xx = clampi(x + dx, 0, w - 1);
-            const int v = frame[(size_t)yy * w + xx];
+            const T v = frame[(size_t)yy * w + xx];
             mx_all = v > mx_all ? v : mx_all;
-            if (dx != 0 || dy != 0)
-                mx_nb = v > mx_nb ? v : mx_nb;
+            if (dx != 0 || dy != 0) {
+                mx_nb = (!nb_set || v > mx_nb) ? v : mx_nb;
+                nb_set = true;
+            }
             // erosion of (img == 0) with border_value = 1: outside pixels are background
             const bool inside = (y + dy >= 0 && y + dy < h && x + dx >= 0 && x + dx < w);
-            any_fg |= inside && frame[(size_t)(y + dy) * w + (x + dx)] != 0;
+            any_fg |= inside && frame[(size_t)(y + dy) * w + (x + dx)] != (T)0;
         }
     int out;
     if (include_plateaus)
@@ -97,8 +104,15 @@ thinning_step_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ erod
 // with zero border (cv2.boxFilter(normalize=False) / cv2.filter2D(ellipse), BORDER_CONSTANT):
 //   mean = s1/count + prior ; var = (s2 - s1^2/count)/(count - 1)
 // Generic fallback (frames wider than 65536 pixels): O(window area) float64 additions per pixel.
+// T = float: the reference's `img.astype(np.int) - prior` truncates float images towards zero first
+template <class T>
+__device__ __forceinline__ double as_int_value(T v) { return (double)v; }
+template <>
+__device__ __forceinline__ double as_int_value<float>(float v) { return (double)(long long)v; }
+
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-image_statistics_kernel(const uint8_t *__restrict__ src, double *__restrict__ mean_out,
+image_statistics_kernel(const T *__restrict__ src, double *__restrict__ mean_out,
                         double *__restrict__ var_out, int h, int w, size_t total, RowSpans se,
                         double prior, int exclude_center, double count)
 {
@@ -108,7 +122,7 @@ image_statistics_kernel(const uint8_t *__restrict__ src, double *__restrict__ me
     const int x = (int)(e % w);
     const size_t rowi = e / w;
     const int y = (int)(rowi % h);
-    const uint8_t *frame = src + (rowi - y) * (size_t)w;
+    const T *frame = src + (rowi - y) * (size_t)w;
     double s1 = 0.0, s2 = 0.0;
     for (int i = 0; i < se.ksize; i++) {
         const int yy = y + i - se.anchor;
@@ -117,15 +131,15 @@ image_statistics_kernel(const uint8_t *__restrict__ src, double *__restrict__ me
         int x0 = x + se.lo[i] - se.anchor, x1 = x + se.hi[i] - 1 - se.anchor;
         x0 = x0 < 0 ? 0 : x0;
         x1 = x1 >= w ? w - 1 : x1;
-        const uint8_t *row = frame + (size_t)yy * w;
+        const T *row = frame + (size_t)yy * w;
         for (int xx = x0; xx <= x1; xx++) {
-            const double d = (double)row[xx] - prior;
+            const double d = as_int_value<T>(row[xx]) - prior;
             s1 += d;
             s2 += d * d;
         }
     }
     if (exclude_center) {
-        const double d = (double)frame[(size_t)y * w + x] - prior;
+        const double d = as_int_value<T>(frame[(size_t)y * w + x]) - prior;
         s1 = s1 - d;
         s2 = s2 - d * d;
     }
@@ -233,9 +247,42 @@ int launch_detect_peaks(const uint8_t *src, uint8_t *dst, int n, int h, int w, i
     size_t total = (size_t)n * h * w;
     if (total == 0)
         return VA_OK;
-    detect_peaks_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(src, dst, h, w, total,
-                                                                          include_plateaus);
+    detect_peaks_kernel<uint8_t><<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(src, dst, h, w, total,
+                                                                                   include_plateaus);
     VA_LAUNCH_CHECK("detect_peaks_kernel");
+    return VA_OK;
+}
+
+int launch_detect_peaks_f32(const float *src, uint8_t *dst, int n, int h, int w, int include_plateaus,
+                            hipStream_t st)
+{
+    size_t total = (size_t)n * h * w;
+    if (total == 0)
+        return VA_OK;
+    detect_peaks_kernel<float><<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(src, dst, h, w, total,
+                                                                                 include_plateaus);
+    VA_LAUNCH_CHECK("detect_peaks_kernel");
+    return VA_OK;
+}
+
+static double element_count(const RowSpans &se, int exclude_center)
+{
+    double count = 0;
+    for (int i = 0; i < se.ksize; i++)
+        count += se.hi[i] > se.lo[i] ? se.hi[i] - se.lo[i] : 0;
+    return exclude_center ? count - 1 : count;
+}
+
+// float32 images: truncated to integers like the reference, then direct window sums in float64
+int launch_image_statistics_f32(const float *src, double *mean_out, double *var_out, int n, int h, int w,
+                                const RowSpans &se, double prior, int exclude_center, hipStream_t st)
+{
+    size_t total = (size_t)n * h * w;
+    if (total == 0)
+        return VA_OK;
+    image_statistics_kernel<float><<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(
+        src, mean_out, var_out, h, w, total, se, prior, exclude_center, element_count(se, exclude_center));
+    VA_LAUNCH_CHECK("image_statistics_kernel");
     return VA_OK;
 }
 
@@ -281,7 +328,7 @@ int launch_image_statistics(const uint8_t *src, double *mean_out, double *var_ou
         VA_LAUNCH_CHECK("image_statistics_prefix_kernel");
         return VA_OK;
     }
-    image_statistics_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(
+    image_statistics_kernel<uint8_t><<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(
         src, mean_out, var_out, h, w, total, se, prior, exclude_center, count);
     VA_LAUNCH_CHECK("image_statistics_kernel");
     return VA_OK;

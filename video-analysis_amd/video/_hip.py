@@ -12,7 +12,7 @@ import numpy as np
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_DIR, "lib", "libvideoanalysis_hip.so")
 
-VA_U8, VA_F32, VA_F64 = 0, 1, 2
+VA_U8, VA_F32, VA_F64, VA_I16 = 0, 1, 2, 3
 BG_NONE, BG_MEAN, BG_EMA, BG_STATIC = 0, 1, 2, 3
 MORPH_ERODE, MORPH_DILATE = 0, 1
 SHAPE_RECT, SHAPE_CROSS, SHAPE_ELLIPSE = 0, 1, 2
@@ -88,6 +88,8 @@ SIGNATURES = {
     "va_gauss_taps_f32": (_i, [_d, C.POINTER(_i), _vp, _i]),
     "va_bg_update": (_i, [_i, _i, _vp, _vp, _vp, _i64, _d, _i, _sz, _vp]),
     "va_welford_u8": (_i, [_vp, _vp, _vp, _i64, _i, _sz, _vp]),
+    "va_mean_any": (_i, [_vp, _i, _vp, _i64, _i, _sz, _vp]),
+    "va_welford_any": (_i, [_vp, _i, _vp, _vp, _i64, _i, _sz, _vp]),
     "va_time_difference_u8": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "va_threshold_u8": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
     "va_mono_mean_u8": (_i, [_vp, _vp, _sz, _vp]),
@@ -99,6 +101,8 @@ SIGNATURES = {
     "va_moments_i64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "va_largest_region": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "va_detect_peaks_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "va_detect_peaks_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "va_image_statistics_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp]),
     "va_mask_thinning_u8": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(_i), _vp]),
     "va_image_statistics_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp]),
     "va_contour_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -107,6 +111,7 @@ SIGNATURES = {
     "va_prepare_u8": (_i, [_vp, _vp] + [_i] * 10 + [_d, _d, _d, _d, _vp]),
     "va_gaussian_noise": (_i, [_vp, _i, _sz, _d, _d, C.c_uint64, C.c_uint64, _vp]),
     "va_resize_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "va_resize_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "va_contour_moments": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "va_pipeline_create": (_i, [C.POINTER(va_config), C.POINTER(_vp)]),
     "va_pipeline_destroy": (_i, [_vp]),

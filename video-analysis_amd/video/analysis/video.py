@@ -13,12 +13,16 @@ def reduce_video(video, function, initial_value=None):
     return result
 
 
+_FRAME_DTYPES = (np.uint8, np.int16, np.float32)
+
+
 def _batches(video, batch):
+    """stacks of `batch` frames; uint8, int16 (FilterTimeDifference) and float32 videos"""
     buf = []
     for frame in video:
         frame = np.asarray(frame)
-        if frame.dtype != np.uint8:
-            raise TypeError("the GPU path expects uint8 frames")
+        if frame.dtype not in _FRAME_DTYPES:
+            raise TypeError("the GPU path takes uint8, int16 or float32 frames, got %s" % frame.dtype)
         buf.append(np.array(frame))
         if len(buf) == batch:
             yield np.stack(buf)
@@ -30,10 +34,19 @@ def _batches(video, batch):
 def measure_mean(video, batch=32):
     """mean of every pixel over time, float64 (reference :26-35)"""
     from .. import ops
-    model = ops.BackgroundModel(video.shape[1:], "mean", dtype=np.uint8)
+    mean, n = None, 0
+    model = None
     for frames in _batches(video, batch):
-        model.process(frames, want_diff=False)
-    return model.state
+        if frames.dtype == np.uint8:            # device-resident state, division-free kernel
+            if model is None:
+                model = ops.BackgroundModel(video.shape[1:], "mean", dtype=np.uint8)
+            model.process(frames, want_diff=False)
+        else:                                   # int16 / float32 frames: NumPy's promotions restated
+            mean = ops.running_mean(frames, mean, n)
+        n += len(frames)
+    if model is not None:
+        return model.state
+    return np.zeros(video.shape[1:]) if mean is None else mean
 
 
 def measure_mean_std(video, batch=32):

@@ -148,8 +148,8 @@ class FilterCrop(VideoFilterBase):
 class FilterResize(VideoFilterBase):
     """resizes the video to `size` = (width, height), or by a factor if `size` is a number
     (reference :252-315: cv2.resize).  `interpolation`: 'auto' (area when the frame shrinks, cubic
-    when it grows), 'nearest', 'linear', 'area', 'cubic'; 'lanczos' is not provided on the GPU.
-    Consecutive resizes contract into one (:299-301).  uint8 frames."""
+    when it grows), 'nearest', 'linear', 'area', 'cubic', 'lanczos'.
+    Consecutive resizes contract into one (:299-301).  uint8 and float32 frames."""
 
     def __init__(self, source, size=None, interpolation="auto", even_dimensions=False):
         if hasattr(size, "__iter__"):
@@ -165,10 +165,8 @@ class FilterResize(VideoFilterBase):
         elif interpolation == "auto":
             shrinks = width * height < source.size[0] * source.size[1]
             self.interpolation = "area" if shrinks else "cubic"
-        elif interpolation in ("nearest", "linear", "area", "cubic"):
+        elif interpolation in ("nearest", "linear", "area", "cubic", "lanczos"):
             self.interpolation = interpolation
-        elif interpolation == "lanczos":
-            raise NotImplementedError("FilterResize: INTER_LANCZOS4 is not provided on the GPU path")
         else:
             raise ValueError("Unknown interpolation method: %s" % (interpolation,))
         while isinstance(source, FilterResize):        # contract with parent resize filters
@@ -180,8 +178,8 @@ class FilterResize(VideoFilterBase):
     def _process_frame(self, frame):
         if self.interpolation:
             frame = np.asarray(frame)
-            if frame.dtype != np.uint8:
-                raise TypeError("FilterResize: only uint8 frames are supported on the GPU path")
+            if frame.dtype not in (np.uint8, np.float32):
+                raise TypeError("FilterResize: uint8 and float32 frames are supported on the GPU path")
             frame = ops.resize(frame, self.size, self.interpolation, color=frame.ndim == 3)
         return super(FilterResize, self)._process_frame(frame)
 

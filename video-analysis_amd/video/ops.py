@@ -179,9 +179,21 @@ class BackgroundModel(object):
         self.n_seen = int(n_seen)
 
 
+TEMPORAL_DTYPES = {np.dtype(np.uint8): _hip.VA_U8, np.dtype(np.int16): _hip.VA_I16,
+                   np.dtype(np.float32): _hip.VA_F32}
+
+
+def _temporal_frames(frames):
+    arr = np.ascontiguousarray(frames)
+    if arr.dtype not in TEMPORAL_DTYPES:
+        raise TypeError("temporal statistics take uint8, int16 or float32 frames on the GPU path, got %s" % arr.dtype)
+    return arr
+
+
 def welford(frames, mean=None, m2=None, n_seen=0):
-    """Welford update of measure_mean_std (video/analysis/video.py:48-50); returns (mean, M2)"""
-    arr = np.ascontiguousarray(frames, np.uint8)
+    """Welford update of measure_mean_std (video/analysis/video.py:48-50); returns (mean, M2).
+    uint8, int16 (FilterTimeDifference) or float32 frames."""
+    arr = _temporal_frames(frames)
     fshape = arr.shape[1:]
     px = int(np.prod(fshape))
     mean = np.zeros(fshape) if mean is None else np.ascontiguousarray(mean, np.float64)
@@ -189,10 +201,29 @@ def welford(frames, mean=None, m2=None, n_seen=0):
     src = _upload(arr)
     dm = _upload(mean)
     dq = _upload(m2)
-    check(_hip.lib().va_welford_u8(src.ptr, dm.ptr, dq.ptr, int(n_seen), arr.shape[0], px, None))
+    if arr.dtype == np.uint8:
+        check(_hip.lib().va_welford_u8(src.ptr, dm.ptr, dq.ptr, int(n_seen), arr.shape[0], px, None))
+    else:
+        check(_hip.lib().va_welford_any(src.ptr, TEMPORAL_DTYPES[arr.dtype], dm.ptr, dq.ptr, int(n_seen),
+                                        arr.shape[0], px, None))
     out = dm.download(fshape, np.float64), dq.download(fshape, np.float64)
     for b in (src, dm, dq):
         _give(b)
+    return out
+
+
+def running_mean(frames, mean=None, n_seen=0):
+    """measure_mean's update `mean*n/(n+1) + frame/(n+1)` (video/analysis/video.py:33) over a batch of
+    uint8 / int16 / float32 frames, NumPy's promotions included; returns the float64 mean"""
+    arr = _temporal_frames(frames)
+    fshape = arr.shape[1:]
+    px = int(np.prod(fshape))
+    mean = np.zeros(fshape) if mean is None else np.ascontiguousarray(mean, np.float64)
+    src = _upload(arr)
+    dm = _upload(mean)
+    check(_hip.lib().va_mean_any(src.ptr, TEMPORAL_DTYPES[arr.dtype], dm.ptr, int(n_seen), arr.shape[0], px, None))
+    out = dm.download(fshape, np.float64)
+    _give(src, dm)
     return out
 
 
@@ -259,15 +290,15 @@ def normalize(frames, fmin, fmax, alpha, tmin):
                          float(alpha), float(tmin), None)
 
 
-INTERPOLATIONS = {"nearest": 0, "linear": 1, "cubic": 2, "area": 3}
+INTERPOLATIONS = {"nearest": 0, "linear": 1, "cubic": 2, "area": 3, "lanczos": 4}
 
 
 def resize(frames, size, interpolation="linear", color=False):
     """cv2.resize(frame, size, interpolation=...) per frame (FilterResize, video/filters.py:310-314);
-    size = (width, height); uint8 frames (H,W) / (N,H,W), with color=True (H,W,C) / (N,H,W,C)"""
+    size = (width, height); uint8 or float32 frames (H,W) / (N,H,W), with color=True (H,W,C) / (N,H,W,C)"""
     frames = np.asarray(frames)
-    if frames.dtype != np.uint8:
-        raise TypeError("resize supports uint8 frames on the GPU path, got %s" % frames.dtype)
+    if frames.dtype not in (np.uint8, np.float32):
+        raise TypeError("resize supports uint8 and float32 frames on the GPU path, got %s" % frames.dtype)
     if interpolation not in INTERPOLATIONS:
         raise ValueError("Unknown interpolation method: %s" % (interpolation,))
     arr, n, fshape, single = _as_batch(frames, 3 if color else 2)
@@ -277,10 +308,11 @@ def resize(frames, size, interpolation="linear", color=False):
         raise ValueError("target size must be positive, got %r" % (size,))
     out_shape = (n, dh, dw) + ((c,) if color else ())
     src = _upload(arr)
-    dst = _take(int(np.prod(out_shape)))
+    dst = _take(int(np.prod(out_shape)) * arr.dtype.itemsize)
     try:
-        check(_hip.lib().va_resize_u8(src.ptr, dst.ptr, n, h, w, c, dh, dw, INTERPOLATIONS[interpolation], None))
-        out = dst.download(out_shape, np.uint8)
+        fn = _hip.lib().va_resize_u8 if arr.dtype == np.uint8 else _hip.lib().va_resize_f32
+        check(fn(src.ptr, dst.ptr, n, h, w, c, dh, dw, INTERPOLATIONS[interpolation], None))
+        out = dst.download(out_shape, arr.dtype)
     finally:
         _give(src, dst)
     return out[0] if single else out
@@ -473,13 +505,21 @@ def contour_moments(contour):
 
 
 def detect_peaks(img, include_plateaus=True):
-    """boolean mask of the local maxima (video/analysis/image.py:267-306), uint8 images"""
+    """boolean mask of the local maxima (video/analysis/image.py:267-306), uint8 or float32 images"""
     a = np.ascontiguousarray(img)
-    if a.dtype != np.uint8 or a.ndim != 2:
-        raise TypeError("detect_peaks expects a 2-d uint8 image on the GPU path")
-    out = _pointwise_u8(_hip.lib().va_detect_peaks_u8, a, a.shape, 1, a.shape[0], a.shape[1],
-                        1 if include_plateaus else 0, None)
-    return out.astype(bool)
+    if a.dtype not in (np.uint8, np.float32) or a.ndim != 2:
+        raise TypeError("detect_peaks expects a 2-d uint8 or float32 image on the GPU path")
+    if a.dtype == np.uint8:
+        out = _pointwise_u8(_hip.lib().va_detect_peaks_u8, a, a.shape, 1, a.shape[0], a.shape[1],
+                            1 if include_plateaus else 0, None)
+        return out.astype(bool)
+    src, dst = _upload(a), _take(a.size)
+    try:
+        check(_hip.lib().va_detect_peaks_f32(src.ptr, dst.ptr, 1, a.shape[0], a.shape[1],
+                                             1 if include_plateaus else 0, None))
+        return dst.download(a.shape, np.uint8).astype(bool)
+    finally:
+        _give(src, dst)
 
 
 def mask_thinning(img):
@@ -501,16 +541,18 @@ def mask_thinning(img):
 
 def image_statistics(img, kernel="box", ksize=5, prior=0.0, exclude_center=False, ret_var=True):
     """local mean (and variance) in a window around every pixel
-    (get_image_statistics, video/analysis/image.py:131-201), uint8 images"""
+    (get_image_statistics, video/analysis/image.py:131-201), uint8 or float32 images (float values are
+    truncated to integers first, as the reference's `img.astype(np.int)` does)"""
     a = np.ascontiguousarray(img)
-    if a.dtype != np.uint8 or a.ndim != 2:
-        raise TypeError("image_statistics expects a 2-d uint8 image on the GPU path")
+    if a.dtype not in (np.uint8, np.float32) or a.ndim != 2:
+        raise TypeError("image_statistics expects a 2-d uint8 or float32 image on the GPU path")
     h, w = a.shape
     src = _upload(a)
     dm = _take(a.size * 8)
     dv = _take(a.size * 8) if ret_var else None
     try:
-        check(_hip.lib().va_image_statistics_u8(src.ptr, dm.ptr, dv.ptr if dv else None, 1, h, w,
+        fn = _hip.lib().va_image_statistics_u8 if a.dtype == np.uint8 else _hip.lib().va_image_statistics_f32
+        check(fn(src.ptr, dm.ptr, dv.ptr if dv else None, 1, h, w,
                                                 {"box": 0, "ellipse": 1, "circle": 1}[kernel],
                                                 int(ksize), float(prior), 1 if exclude_center else 0,
                                                 None))
