@@ -526,11 +526,17 @@ ema_row_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, co
 //     sub-chunk's next frame is requested as soon as its current one is staged -- two phases ahead.
 namespace is {
 
+#ifndef ROWIS_CPOS
+#define ROWIS_CPOS 4         // barrier C sits at ROWIS_CPOS / 8 of the compute waves' row pass
+#endif
 constexpr int kTW = 512;                 // loader threads: 8 waves (2 per SIMD)
 constexpr int kTC = 512;                 // compute threads: 8 waves (2 per SIMD)
-constexpr int kP2 = 15;                  // outputs per compute thread and half (odd: conflict-free LDS strides)
-constexpr int kHoff = kP2 * kTC;         // 7680 = 120 * 64 floats between the halves of a lane's pair
-constexpr int kXW = 2 * kHoff;           // window starts per buffer
+// outputs per compute thread and half: a template parameter P2 (odd: conflict-free LDS strides).  15 fits every
+// shape the plan accepts; 13 is chosen when a sub-chunk still fits (1080p x 3 at one workgroup per CU: 13 086 of
+// 13 312 window positions in use instead of 13 086 of 15 360, i.e. 13 % fewer FMAs issued on padding).
+constexpr int kP2Max = 15;
+constexpr int hoff_of(int p2) { return p2 * kTC; }       // floats between the halves of a lane's pair (multiple of 64)
+constexpr int xw_of(int p2) { return 2 * p2 * kTC; }     // window starts per buffer
 constexpr int kNS = 7;                   // float4 loads per loader thread and sub-chunk
 constexpr int kSeg = 4;                  // row pieces per sub-chunk
 
@@ -576,33 +582,46 @@ __host__ __device__ inline Tab make_tab(int cs_in, int L, int total, int h, int 
 
 // a sub-chunk of L flat samples fits: at most kSeg row pieces, its padded blocks inside the two halves,
 // its loads inside kNS float4 per loader thread
-inline bool fits(long long L, int rw, int halo)
+inline bool fits(long long L, int rw, int halo, int p2)
 {
     const long long ns = (L + rw - 2) / rw + 1;
-    return ns <= kSeg && L + ns * (2 * halo + 16) + 8 <= (long long)kXW &&
+    return ns <= kSeg && L + ns * (2 * halo + 16) + 8 <= (long long)xw_of(p2) &&
            (L + 2 * halo + 8 + 3) / 4 <= (long long)kNS * kTW;
 }
 
-template <int C, int RAD>
+template <int C, int RAD, int kP2>
 __global__ void __launch_bounds__(kTW + kTC)   // (HALO = RAD C <= 108 < kTW)
 row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, const float *__restrict__ bg,
                   float *__restrict__ bg_out, long long n_seen, float rate, int nframes, int h, int w, int L,
                   TapsF32 taps)
 {
     constexpr int HALO = RAD * C, NT = 2 * RAD + 1;
+    constexpr int kHoff = hoff_of(kP2), kXW = xw_of(kP2);
     constexpr int NIN = kP2 + 2 * HALO;              // inputs a compute thread walks over
     constexpr int XCAP = kXW + 2 * HALO + 8;   // floats per buffer
     __shared__ __attribute__((aligned(16))) float Xs[2][XCAP];
-    __shared__ unsigned short smap[2][kNS][kTW];
+    // where a loader thread's loaded float4s are staged: kNS 16-bit X offsets per thread and sub-chunk,
+    // packed so that ONE 16-byte LDS read fetches them all (seven 2-byte reads were seven LDS round trips
+    // per staging, each behind the compute waves' own LDS traffic)
+    static_assert(kNS <= 8, "the staging map of a thread is one 16-byte LDS read");
+    __shared__ __attribute__((aligned(16))) unsigned short smap[2][kTW][8];
 
     const bool ema = bg != nullptr;                  // uniform
     const int rw = w * C, total = h * rw;
     const size_t fstride = (size_t)total;
+    const int f0 = ema ? 0 : blockIdx.y, f1 = ema ? nframes : blockIdx.y + 1;
+    // Every CU runs the same phases in lock step, so the whole chip would load, then store, in bursts (the
+    // copy-out stores block their waves for as long as the memory system takes to accept them: 0.7 of this
+    // kernel's 4.4 ms).  A one-time start skew between workgroups -- nothing re-synchronises them afterwards --
+    // spreads the bursts: 4.37 -> 4.16 ms per 256 x 1080p x 3 (0, 2, 4 and 8 groups of about half a phase
+    // measured).  Only where a workgroup runs long enough to repay the wait (the whole batch, EMA mode).
+    if (f1 - f0 >= 16)
+        for (int k = 0; k < (int)(blockIdx.x & 7); k++)
+            __builtin_amdgcn_s_sleep(127);
     const bool loader = threadIdx.x < kTW;           // wave-uniform
     const int tid = loader ? threadIdx.x : threadIdx.x - kTW;
     const Tab T0 = make_tab((2 * blockIdx.x) * L, L, total, h, rw, HALO);
     const Tab T1 = make_tab((2 * blockIdx.x + 1) * L, L, total, h, rw, HALO);
-    const int f0 = ema ? 0 : blockIdx.y, f1 = ema ? nframes : blockIdx.y + 1;
 
     // results of a phase leave as 16-byte pieces: output float4 fo of piece k sits at
     // O[fo - rs[k] + D[k] - HALO] (O = the buffer itself, indexed by window start).  Loader waves only:
@@ -613,15 +632,27 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
         int fo0 = T.cs + 4 * tid;
         asm volatile("" : "+v"(fo0));
         const int nsl = (T.ce - T.cs + 4 * kTW - 1) / (4 * kTW);        // uniform
-        for (int m = 0; m < nsl; m++) {
+        // the LDS read of slot m + 1 is in flight while slot m's store waits to be accepted
+        auto fetch = [&](int m) {
             const int fo = fo0 + 4 * kTW * m;
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
             if (fo < T.ce) {
                 int p = fo - T.rs[0] + T.D[0];
 #pragma unroll
                 for (int k = 1; k < kSeg; k++)
                     if (T.qa[k] < T.qb[k] && fo >= T.rs[k])
                         p = fo - T.rs[k] + T.D[k];
-                const f4 v = *reinterpret_cast<const f4 *>(O + (p - HALO));
+                v = *reinterpret_cast<const f4 *>(O + (p - HALO));
+            }
+            return v;
+        };
+        f4 nxt = fetch(0);
+        for (int m = 0; m < nsl; m++) {
+            const int fo = fo0 + 4 * kTW * m;
+            const f4 v = nxt;
+            if (m + 1 < nsl)
+                nxt = fetch(m + 1);
+            if (fo < T.ce) {
 #ifdef ROWIS_NO_STORE
                 if (v.x == 123.456f)
 #endif
@@ -648,7 +679,7 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
                             info = ((q + T.D[k]) >> 2) + 1;
                     }
                 }
-                smap[sub][m][tid] = (unsigned short)info;
+                smap[sub][tid][m] = (unsigned short)info;
             }
         };
         make_map(T0, 0);
@@ -688,9 +719,11 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
         auto stage = [&](int sub, float *X, f4 (&st)[kNS], bool first) {
             int t = tid;
             asm volatile("" : "+v"(t));
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const u4v map = *reinterpret_cast<const u4v *>(&smap[sub][t][0]);
 #pragma unroll
             for (int m = 0; m < kNS; m++) {
-                const int info = smap[sub][m][t];
+                const int info = (int)((map[m >> 1] >> (16 * (m & 1))) & 0xFFFFu);
                 if (info != 0) {
                     f4 v = ld[m];
                     if (ema) {
@@ -799,7 +832,7 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
         for (int i = 0; i < kInputsRun; i++) {
             // barrier C of the loader waves (the buffer they copied out may be staged again): passed here,
             // half-way, so that neither side waits for long
-            if (i == kInputsRun / 2)
+            if (i == kInputsRun * ROWIS_CPOS / 8)
                 lds_barrier();
             const f2 x = xs[i % kAhead];
             if (i + kAhead < NIN)
@@ -1322,8 +1355,9 @@ static int g_f32_col_generic = 0;   // test hook: the runtime-radius column kern
 static int g_f32_row_generic = 0;   // test hook: the runtime-radius row kernel for every radius
 
 // the compile-time-radius row kernel: sub-chunk length (0: shape not supported)
-static int plan_rows_is(int h, int w, int c, int r, int cus, const TapsF32 &taps)
+static int plan_rows_is(int h, int w, int c, int r, int cus, const TapsF32 &taps, int *p2_out)
 {
+    *p2_out = is::kP2Max;
     const int halo = r * c, rw = w * c;
     if ((c != 1 && c != 3) || w <= r || rw % 4 != 0)
         return 0;
@@ -1336,14 +1370,18 @@ static int plan_rows_is(int h, int w, int c, int r, int cus, const TapsF32 &taps
     long long L = ((total + 2 * cus - 1) / (2 * cus) + 3) / 4 * 4;
     if (L < 1024)
         L = total < 1024 ? (total + 3) / 4 * 4 : 1024;
-    while (L > 4 && !is::fits(L, rw, halo))
+    if (is::fits(L, rw, halo, 13)) {                   // the equal split fits the narrower layout
+        *p2_out = 13;
+        return (int)L;
+    }
+    while (L > 4 && !is::fits(L, rw, halo, is::kP2Max))
         L -= 4;
-    if (!is::fits(L, rw, halo) || L < 4 * c)
+    if (!is::fits(L, rw, halo, is::kP2Max) || L < 4 * c)
         return 0;
     return (int)L;
 }
 
-template <int C>
+template <int C, int P2>
 static bool launch_row_is(int r, unsigned nwg, unsigned ny, const float *src, float *tmp, const float *bg,
                           float *bg_out, long long n_seen, float rate, int n, int h, int w, int L,
                           const TapsF32 &taps, hipStream_t st)
@@ -1351,7 +1389,7 @@ static bool launch_row_is(int r, unsigned nwg, unsigned ny, const float *src, fl
     const dim3 grid(nwg, ny);
 #define VA_ROW_IS(RAD)                                                                                        \
     case RAD:                                                                                                 \
-        is::row_is_f32_kernel<C, RAD><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, bg_out, n_seen, rate, n, h, w, L, taps); \
+        is::row_is_f32_kernel<C, RAD, P2><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, bg_out, n_seen, rate, n, h, w, L, taps); \
         return true;
     switch (r) {
         VA_ROW_IS(4) VA_ROW_IS(8) VA_ROW_IS(12) VA_ROW_IS(16) VA_ROW_IS(20) VA_ROW_IS(24) VA_ROW_IS(28) VA_ROW_IS(32)
@@ -1404,13 +1442,18 @@ int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, const f
                         2 * (size_t)kNV * kT * sizeof(unsigned short);
     const int nwg = (plan.nchunks + 1) / 2;          // two sub-chunks per workgroup
     // radii of common integer sigmas: the input-stationary kernel (one workgroup per CU)
-    const int Lis = g_f32_row_generic ? 0 : plan_rows_is(h, w, c, r, cus, taps);
+    int p2 = is::kP2Max;
+    const int Lis = g_f32_row_generic ? 0 : plan_rows_is(h, w, c, r, cus, taps, &p2);
     bool rows_done = false;
     if (Lis > 0) {
         const long long total = (long long)h * rw;
         const unsigned nwg2 = (unsigned)(((total + Lis - 1) / Lis + 1) / 2), ny = bg ? 1u : (unsigned)n;
-        rows_done = c == 1 ? launch_row_is<1>(r, nwg2, ny, src, scratch, bg, bg_out, n_seen, (float)rate, n, h, w, Lis, taps, st)
-                           : launch_row_is<3>(r, nwg2, ny, src, scratch, bg, bg_out, n_seen, (float)rate, n, h, w, Lis, taps, st);
+#define VA_ROW_IS_ARGS r, nwg2, ny, src, scratch, bg, bg_out, n_seen, (float)rate, n, h, w, Lis, taps, st
+        if (p2 == 13)
+            rows_done = c == 1 ? launch_row_is<1, 13>(VA_ROW_IS_ARGS) : launch_row_is<3, 13>(VA_ROW_IS_ARGS);
+        else
+            rows_done = c == 1 ? launch_row_is<1, 15>(VA_ROW_IS_ARGS) : launch_row_is<3, 15>(VA_ROW_IS_ARGS);
+#undef VA_ROW_IS_ARGS
     }
     if (rows_done) {
     } else if (bg) {
