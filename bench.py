@@ -322,7 +322,8 @@ def roofline_of(stage, px_bytes_table, units, workload, peak=HBM_PEAK_GBS):
     if os.path.exists(tpath):
         try:
             table = json.load(open(tpath))
-            traffic = table.get(workload, {}).get(name)
+            stages = table.get(workload, {})
+            traffic = stages.get(name, stages.get(name.replace("_mask8", "")))    # (one kernel, two epilogues)
             if traffic is not None:
                 source = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                           "command (%s), not measured in this run" % table.get("_source", {}).get(workload, "r01_j"))
