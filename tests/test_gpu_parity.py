@@ -578,7 +578,7 @@ def test_small_stencils_peaks_thinning_statistics(ops, oracle):
     """N2: detect_peaks / mask_thinning (python method) / get_image_statistics"""
     from video.analysis import image
     rng = np.random.default_rng(71)
-    for shape in ((1, 1), (1, 9), (7, 1), (40, 53), (128, 200)):
+    for shape in ((1, 1), (1, 9), (7, 1), (40, 53), (128, 200), (5, 4), (1, 8), (33, 64), (2, 12)):   # (w % 4 == 0: four pixels per thread)
         img = rng.integers(0, 6, shape, dtype=np.uint8) * rng.integers(0, 2, shape, dtype=np.uint8)
         smooth = (rng.integers(0, 256, shape) // 32 * 32).astype(np.uint8)     # plateaus
         for im in (img, smooth, np.zeros(shape, np.uint8), np.full(shape, 9, np.uint8)):
