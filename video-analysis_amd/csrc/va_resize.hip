@@ -37,13 +37,14 @@ __global__ void __launch_bounds__(kBlock)
 resize_nn_kernel(const T *__restrict__ src, T *__restrict__ dst, const int *__restrict__ xofs,
                  const int *__restrict__ yofs, int sh, int sw, int c, int dh, int dw, size_t total)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= total)
+    // grid = (samples of an output row, output rows, frames): no 64-bit divisions per sample
+    const int e = blockIdx.x * kBlock + threadIdx.x;                 // dx * c + ch
+    if (e >= dw * c)
         return;
-    const int ch = (int)(i % c);
-    const size_t p = i / c;
-    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
-    const size_t f = p / ((size_t)dw * dh);
+    (void)total;
+    const int dx = c == 1 ? e : e / c, ch = e - dx * c, dy = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const size_t i = ((f * dh + dy) * (size_t)dw) * c + e;
     dst[i] = src[(f * sh + yofs[dy]) * (size_t)sw * c + (size_t)xofs[dx] * c + ch];
 }
 
@@ -54,13 +55,14 @@ resize_taps_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, c
                    const short *__restrict__ ibeta, int xmax, int sh, int sw, int c, int dh, int dw,
                    size_t total)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= total)
+    // grid = (samples of an output row, output rows, frames): no 64-bit divisions per sample
+    const int e = blockIdx.x * kBlock + threadIdx.x;                 // dx * c + ch
+    if (e >= dw * c)
         return;
-    const int ch = (int)(i % c);
-    const size_t p = i / c;
-    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
-    const size_t f = p / ((size_t)dw * dh);
+    (void)total;
+    const int dx = c == 1 ? e : e / c, ch = e - dx * c, dy = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const size_t i = ((f * dh + dy) * (size_t)dw) * c + e;
     const uint8_t *frame = src + f * (size_t)sh * sw * c;
     const int sx = xofs[dx];
     int rows[KS];
@@ -113,13 +115,14 @@ resize_taps_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, c
                        const float *__restrict__ beta, int xmax, int sh, int sw, int c, int dh, int dw,
                        size_t total)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= total)
+    // grid = (samples of an output row, output rows, frames): no 64-bit divisions per sample
+    const int e = blockIdx.x * kBlock + threadIdx.x;                 // dx * c + ch
+    if (e >= dw * c)
         return;
-    const int ch = (int)(i % c);
-    const size_t p = i / c;
-    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
-    const size_t f = p / ((size_t)dw * dh);
+    (void)total;
+    const int dx = c == 1 ? e : e / c, ch = e - dx * c, dy = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const size_t i = ((f * dh + dy) * (size_t)dw) * c + e;
     const float *frame = src + f * (size_t)sh * sw * c;
     const int sx = xofs[dx];
     float out = 0.f;
@@ -155,13 +158,14 @@ __global__ void __launch_bounds__(kBlock)
 resize_area_fast_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, int isx, int isy,
                             int wfull, int sh, int sw, int c, int dh, int dw, size_t total)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= total)
+    // grid = (samples of an output row, output rows, frames): no 64-bit divisions per sample
+    const int e = blockIdx.x * kBlock + threadIdx.x;                 // dx * c + ch
+    if (e >= dw * c)
         return;
-    const int ch = (int)(i % c);
-    const size_t p = i / c;
-    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
-    const size_t f = p / ((size_t)dw * dh);
+    (void)total;
+    const int dx = c == 1 ? e : e / c, ch = e - dx * c, dy = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const size_t i = ((f * dh + dy) * (size_t)dw) * c + e;
     const float *frame = src + f * (size_t)sh * sw * c + ch;
     const int sx0 = dx * isx, sy0 = dy * isy;
     float sum = 0.f;
@@ -178,13 +182,14 @@ __global__ void __launch_bounds__(kBlock)
 resize_area_fast_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int isx, int isy,
                         int wfull, int sh, int sw, int c, int dh, int dw, size_t total)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= total)
+    // grid = (samples of an output row, output rows, frames): no 64-bit divisions per sample
+    const int e = blockIdx.x * kBlock + threadIdx.x;                 // dx * c + ch
+    if (e >= dw * c)
         return;
-    const int ch = (int)(i % c);
-    const size_t p = i / c;
-    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
-    const size_t f = p / ((size_t)dw * dh);
+    (void)total;
+    const int dx = c == 1 ? e : e / c, ch = e - dx * c, dy = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const size_t i = ((f * dh + dy) * (size_t)dw) * c + e;
     const uint8_t *frame = src + f * (size_t)sh * sw * c + ch;
     const int sx0 = dx * isx, sy0 = dy * isy;
     int sum = 0, count = 0;
@@ -219,13 +224,14 @@ resize_area_kernel(const T *__restrict__ src, T *__restrict__ dst, const DecAlph
                    const int *__restrict__ xstart, const DecAlpha *__restrict__ ytab,
                    const int *__restrict__ ystart, int sh, int sw, int c, int dh, int dw, size_t total)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= total)
+    // grid = (samples of an output row, output rows, frames): no 64-bit divisions per sample
+    const int e = blockIdx.x * kBlock + threadIdx.x;                 // dx * c + ch
+    if (e >= dw * c)
         return;
-    const int ch = (int)(i % c);
-    const size_t p = i / c;
-    const int dx = (int)(p % dw), dy = (int)((p / dw) % dh);
-    const size_t f = p / ((size_t)dw * dh);
+    (void)total;
+    const int dx = c == 1 ? e : e / c, ch = e - dx * c, dy = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const size_t i = ((f * dh + dy) * (size_t)dw) * c + e;
     const T *frame = src + f * (size_t)sh * sw * c + ch;
     float sum = 0.f;
     bool firstrow = true;
@@ -370,12 +376,24 @@ static int launch_resize(const T *src, T *dst, int n, int sh, int sw, int c, int
     VA_REQUIRE(src && dst && scratch, "resize: NULL argument");
     VA_REQUIRE(n >= 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && c > 0 && c <= 4, "resize: bad shape");
     VA_REQUIRE(mode >= 0 && mode <= 4, "resize: interpolation must be 0 nearest, 1 linear, 2 cubic, 3 area or 4 lanczos4");
+    VA_REQUIRE(dh <= 65535, "resize: target frames of more than 65535 rows are not supported");
     const size_t total = (size_t)n * dh * dw * c;
     if (total == 0)
         return VA_OK;
     const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
     const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
-    const unsigned grid = (unsigned)cdiv((long long)total, kBlock);
+    // one launch covers up to 65535 frames (gridDim.z); longer batches go out in pieces (same tables)
+    if (n > 65535) {
+        for (int a = 0; a < n; a += 65535) {
+            const int k = n - a < 65535 ? n - a : 65535;
+            int rc = launch_resize<T>(src + (size_t)a * sh * sw * c, dst + (size_t)a * dh * dw * c, k, sh, sw, c, dh, dw, mode,
+                                      scratch, st);
+            if (rc)
+                return rc;
+        }
+        return VA_OK;
+    }
+    const dim3 grid((unsigned)cdiv((long long)dw * c, kBlock), (unsigned)dh, (unsigned)n);
     char *base = (char *)scratch;
     size_t used = 0;
     auto push = [&](const void *host, size_t bytes, void **dev) -> int {
