@@ -481,7 +481,7 @@ def main():
     distributed = dist.is_initialized()
 
     from video.engine import FrameEngine
-    from video.sharding import gather_counts
+    from video.sharding import CountGather, gather_counts
 
     if args.workload in F32_WORKLOADS:
         if world > 1:
@@ -513,7 +513,10 @@ def main():
     # k + 1 is painted into the other)
     labels = [torch.empty((batch, h, w), dtype=torch.int32, device=device) for _ in range(2 if overlap else 1)] if ccl else None
     mask = None if ccl else torch.empty((batch, h, w), dtype=torch.uint8, device=device)
-    counts = torch.zeros((batch,), dtype=torch.int32, device=device)
+    # two count buffers: the gather of step k (asynchronous, finished one step later) reads one while the
+    # labelling of step k + 1 writes the other
+    counts2 = [torch.zeros((batch,), dtype=torch.int32, device=device) for _ in range(2)]
+    counts = counts2[0]
     steps_morph = (("dilate", "rect", morph), ("erode", "rect", morph)) if morph else ()
     from video import _hip
     L = _hip.lib(dev_index)
@@ -541,8 +544,8 @@ def main():
 
     def run_chain(e, i=0):
         if ccl:
-            e.run_device(frames.data_ptr(), batch, None, None, labels[i % len(labels)].data_ptr(), counts.data_ptr(),
-                         None, stream.cuda_stream)
+            e.run_device(frames.data_ptr(), batch, None, None, labels[i % len(labels)].data_ptr(),
+                         counts2[i % 2].data_ptr(), None, stream.cuda_stream)
         else:
             e.run_device(frames.data_ptr(), batch, None, mask.data_ptr(), None, None, None, stream.cuda_stream)
 
@@ -554,11 +557,24 @@ def main():
                                             n_local=batch, device=wire)
             eng.set_background(st0, seen0)
         run_chain(eng, i)
-        if world > 1:       # the path's only exchange: object counts of every shard, RCCL over xGMI
-            return gather_counts(counts if args.backend == "nccl" else counts.cpu(), total)
-        return counts
+        if world > 1:
+            # the path's only exchange: object counts of every shard, RCCL over xGMI.  Step i's all-gather is
+            # enqueued now and collected after step i + 1 has been launched, so the compute stream never waits
+            # for the collective (every step's gather still completes inside the timed region: fence())
+            done = gather.finish()
+            c = counts2[i % 2] if ccl else counts
+            gather.start(c if args.backend == "nccl" else c.cpu())
+            return done
+        return counts2[i % 2] if ccl else counts
+
+    gather = CountGather(total) if world > 1 else None
+    last_counts = [None]
 
     def fence():
+        if gather is not None:
+            got = gather.finish()
+            if got is not None:
+                last_counts[0] = got
         if overlap:
             eng.fence(stream.cuda_stream)      # the label-image writes on the pipeline's own stream
         torch.cuda.synchronize(device)
@@ -589,8 +605,11 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    if world > 1 and all_counts.numel() != total:
-        raise SystemExit("count gather returned %d entries for %d frames" % (all_counts.numel(), total))
+    if world > 1:
+        all_counts = last_counts[0]                    # (the last step's gather, collected by fence())
+        if all_counts is None or all_counts.numel() != total:
+            raise SystemExit("count gather returned %s entries for %d frames"
+                             % (None if all_counts is None else all_counts.numel(), total))
 
     total_frames = total * args.steps
     fps = total_frames / dt
@@ -650,7 +669,7 @@ def main():
                 check = {"k": np.int64(k), "state": state0, "n_seen": np.int64(seen0)}
                 if ccl:
                     check["labels"] = labels[args.steps % len(labels)][:k].cpu().numpy()
-                    check["counts"] = counts[:k].cpu().numpy()
+                    check["counts"] = counts2[args.steps % 2][:k].cpu().numpy()
                 else:
                     check["mask"] = mask[:k].cpu().numpy()
             # (2) the device's own fill / copy rates on the chain's largest buffer (second denominator)

@@ -36,6 +36,15 @@ def _worker(rank, world, port, n_frames, out_dir):
     local = torch.from_numpy(full[a:b].astype(np.int32))
     got = gather_counts(local, n_frames)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), got.numpy())
+    # the asynchronous form bench.py uses: step k's gather is collected after step k + 1 has started
+    from video.sharding import CountGather
+    g = CountGather(n_frames)
+    assert g.finish() is None
+    g.start(local)
+    g.start(local + 1)                                   # (collects the first one internally)
+    second = g.finish()
+    assert g.finish() is None
+    np.save(os.path.join(out_dir, "async_rank%d.npy" % rank), second.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,6 +61,7 @@ def test_gather_counts_two_ranks_gloo(tmp_path, n_frames):
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         assert got.dtype == np.int32 and np.array_equal(got, full)      # frame order, every rank
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "async_rank%d.npy" % r)), full + 1)
 
 
 # ---------------------------------------------------------------------------- one video, several shards

@@ -117,3 +117,56 @@ def background_handoff(advance, shape, dtype, first_state=None, first_seen=0, n_
         dist.send(st, dst=rank + 1, group=group)
         dist.send(torch.tensor([seen + int(n_local)], dtype=torch.int64, device=st.device), dst=rank + 1, group=group)
     return state, seen
+
+
+class CountGather(object):
+    """the per-step count gather, off the critical path: `start(counts)` enqueues the all-gather of this
+    step's per-frame counts (asynchronously: the collective runs on the backend's own stream once the
+    counts are ready) and `finish()` hands back the gathered counts of the step started LAST, in frame
+    order.  A caller that finishes step k's gather only after it has launched step k + 1's chain never
+    stalls its compute stream on the collective.  Give consecutive `start` calls different count
+    buffers (the next step's labelling overwrites the one it uses)."""
+
+    def __init__(self, n_frames, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_frames = int(n_frames)
+        self.sizes = shard_sizes(self.n_frames, self.world)
+        self.cap = max(self.sizes) if self.sizes else 0
+        self._pending = None            # (work handle or None, recv tensor, send tensor kept alive)
+
+    def start(self, local_counts):
+        import torch
+        import torch.distributed as dist
+        if self._pending is not None:
+            self.finish()
+        if self.world == 1:
+            self._pending = (None, local_counts, None)
+            return
+        if local_counts.numel() != self.sizes[self.rank]:
+            raise ValueError("rank %d holds %d counts, its shard has %d frames"
+                             % (self.rank, local_counts.numel(), self.sizes[self.rank]))
+        recv = torch.empty(self.world * self.cap, dtype=torch.int32, device=local_counts.device)
+        send = local_counts.contiguous()
+        if send.numel() != self.cap:                    # ragged shards: pad to the largest one
+            send = torch.zeros(self.cap, dtype=torch.int32, device=local_counts.device)
+            send[:local_counts.numel()] = local_counts
+        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        self._pending = (work, recv, send)
+
+    def finish(self):
+        """gathered counts of the last started step (None if nothing is pending); makes the current
+        stream wait for the collective, not the host"""
+        import torch
+        if self._pending is None:
+            return None
+        work, recv, _send = self._pending
+        self._pending = None
+        if work is None:
+            return recv
+        work.wait()
+        if all(sz == self.cap for sz in self.sizes):
+            return recv
+        return torch.cat([recv[r * self.cap:r * self.cap + self.sizes[r]] for r in range(self.world)])
