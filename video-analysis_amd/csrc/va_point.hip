@@ -10,6 +10,8 @@
 // registers and walks the frames of the batch in order (state is read and written once per
 // batch, not once per frame).  Built with -ffp-contract=off: the float64 expression
 // mean*n/(n+1) + frame/(n+1) is evaluated with exactly NumPy's roundings (no fma).
+#include <math.h>
+
 #include "va_common.h"
 
 namespace va {
@@ -104,13 +106,24 @@ bg_reciprocals_kernel(double *__restrict__ y, long long n_seen, int n)
 // IEEE division either way), which saves the launch of bg_reciprocals_kernel and its place in the queue
 struct RecipArgs {
     double r[256];
+    // lo[f] = 1/d - hi(r[f]) to 2^-53 relative, hi() = r[f] with its low 9 significand bits cleared: the
+    // second quotient frame/(n + 1) of an 8-bit frame value then takes TWO operations, p = frame * hi (exact:
+    // 8 + 44 bits) and fma(frame, lo, p) = RN(frame/d (1 + 2^-96)), which is RN(frame/d) for every d < 2^40
+    // (a non-dyadic quotient stays 2^-54 / d away from every rounding midpoint; tools/verify_small_div.c checks
+    // all d <= 2^24 and random d up to 2^40 exhaustively over the 256 frame values)
+    double lo[256];
     __device__ double operator[](int f) const { return r[f]; }
 };
+__device__ __forceinline__ double clear_low9(double y)        // (uniform operand: scalar ALU)
+{
+    return __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, y) & ~0x1FFull);
+}
 
 // BOUNDED: the caller vouches that every mean lies in [0, 255] (true for a state that started at zero or
 // inside that range: a mean of uint8 values stays there up to rounding), so |frame - mean| < 256 and the
 // saturation of the difference -- one of the 14 operations per pixel -- can go
-template <int V, typename RECIP, bool BOUNDED>
+// SPLIT (RECIP = RecipArgs only): the second quotient in two operations, see RecipArgs::lo
+template <int V, typename RECIP, bool BOUNDED, bool SPLIT = false>
 __global__ void __launch_bounds__(kBlock)
 bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__ diff,
                        double *__restrict__ mean, const RECIP recip, long long n_seen, int n, size_t px)
@@ -154,11 +167,21 @@ bg_mean_u8_fast_kernel(const uint8_t *__restrict__ frames, uint8_t *__restrict__
             memcpy(p, &cur[j], V);
             const double dn = (double)(n_seen + f), dn1 = (double)(n_seen + f + 1);
             const double y = recip[f];
+            double yh = 0.0, yl = 0.0;
+            if constexpr (SPLIT) {
+                yh = clear_low9(y);
+                yl = recip.lo[f];
+            }
 #pragma unroll
             for (int k = 0; k < V; k++) {
                 const double fr = (double)p[k];
                 o[k] = BOUNDED ? (uint8_t)(int)fabs(fr - m[k]) : sat_u8_trunc(fabs(fr - m[k]));
-                m[k] = div_by_uniform(m[k] * dn, dn1, y) + div_by_uniform(fr, dn1, y);
+                double q2;
+                if constexpr (SPLIT)
+                    q2 = fma(fr, yl, fr * yh);
+                else
+                    q2 = div_by_uniform(fr, dn1, y);
+                m[k] = div_by_uniform(m[k] * dn, dn1, y) + q2;
             }
             if (diff) {
                 v2u v;
@@ -481,10 +504,29 @@ int launch_bg(int mode, int dtype, const void *frames, void *diff, void *state, 
             const bool wide = px % 16 == 0 && aligned(fr, 16) && (!df || aligned(df, 16));
             if (vec && n <= 256) {
                 RecipArgs ra;
-                for (int f = 0; f < 256; f++)
-                    ra.r[f] = 1.0 / (double)(n_seen + (f < n ? f : 0) + 1);
-                if (wide && mean_in_u8_range)
+                for (int f = 0; f < 256; f++) {
+                    const double d = (double)(n_seen + (f < n ? f : 0) + 1), y = 1.0 / d;
+                    unsigned long long bits;
+                    memcpy(&bits, &y, 8);
+                    bits &= ~0x1FFull;
+                    double yh;
+                    memcpy(&yh, &bits, 8);
+                    ra.r[f] = y;
+                    ra.lo[f] = fma(y, fma(-d, y, 1.0), y - yh);      // (host fma: correctly rounded)
+                }
+#ifdef BG_NO_SPLIT                                                    // (A/B builds: tools/debug/build_variant.sh)
+                const bool split = false;
+#else
+                const bool split = n_seen + n < (1ll << 40);         // where the two-operation quotient is proven
+#endif
+                if (wide && mean_in_u8_range && split)
+                    bg_mean_u8_fast_kernel<16, RecipArgs, true, true><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
+                        fr, df, (double *)state, ra, n_seen, n, px);
+                else if (wide && mean_in_u8_range)
                     bg_mean_u8_fast_kernel<16, RecipArgs, true><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
+                        fr, df, (double *)state, ra, n_seen, n, px);
+                else if (wide && split)
+                    bg_mean_u8_fast_kernel<16, RecipArgs, false, true><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
                         fr, df, (double *)state, ra, n_seen, n, px);
                 else if (wide)
                     bg_mean_u8_fast_kernel<16, RecipArgs, false><<<cdiv((long long)(px / 16), kBlock), kBlock, 0, st>>>(
