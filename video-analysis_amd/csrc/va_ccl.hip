@@ -1336,6 +1336,45 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         __syncthreads();
 
         // ---- phase B: lanes write 4 consecutive pixels each, 1 KiB per wave-instruction
+#ifndef VA_PAINT_NO_INTERLEAVE
+        // The block's rows are contiguous in the label image.  Where a row is one chunk (w <= 2048) and the
+        // block is whole, its waves write the span's 1 KiB pieces INTERLEAVED (wave v: pieces v, v + 4, ...)
+        // instead of one 7.5 KiB row each: at any moment the block's stores fall into neighbouring KiB
+        // (tools/microbench/fill_rate.hip: the fewer consecutive KiB a wave streams, the closer to the fill rate).
+        // (h % 4 == 0: a block never straddles two frames and its four rows are valid or invalid together)
+        const bool whole = w32 <= kWave && vec_ok && (w & 3) == 0 && (h & (kRowsPerBlock - 1)) == 0 && c.valid;
+        if (whole) {
+            const int y0 = c.y - wv;                                 // first row of the block
+            int32_t *span = L + (size_t)y0 * w;
+            const int span_px = kRowsPerBlock * w, pieces = (span_px + 255) >> 8;
+            for (int g = wv; g < pieces; g += kRowsPerBlock) {
+                const int off = g * 256 + c.lane * 4;
+                if (off >= span_px)
+                    continue;
+                const int r = (off >= w) + (off >= 2 * w) + (off >= 3 * w);
+                static_assert(kRowsPerBlock == 4, "row of a span offset: three comparisons");
+                const int x = off - r * w;
+                const int wl = x >> 5;
+                const uint32_t mw = s_m[r][wl], hd = s_heads[r][wl];
+                int v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int bit = (x & 31) + j;
+                    v[j] = 0;
+                    if ((mw >> bit) & 1u) {
+                        const int k = __popc(hd & (0xFFFFFFFFu >> (31 - bit))) - 1;
+                        v[j] = s_lab[r][wl][k];
+                    }
+                }
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i val = {v[0], v[1], v[2], v[3]};
+                if (kNtStores)
+                    __builtin_nontemporal_store(val, reinterpret_cast<v4i *>(span + off));
+                else
+                    *reinterpret_cast<v4i *>(span + off) = val;
+            }
+        } else
+#endif
         if (c.valid) {
             const int xbase = w0 << 5;
 #pragma unroll
