@@ -254,8 +254,15 @@ def cpu_baseline_f32_main(argv):
     n = frames.shape[0]
     t0 = time.perf_counter()
     diff, _ = O.bg_ema_f32(frames, rate=rate)
-    O.gaussian_f32(diff, sigma)
+    ref = O.gaussian_f32(diff, sigma)
     dt = time.perf_counter() - t0
+    if len(argv) > 3 and argv[3] != "-":
+        # the GPU's output for these very frames (a fresh pipeline, i.e. the same zero state): bit patterns
+        ck = np.load(argv[3])
+        k = int(ck["k"])
+        same = bool(np.array_equal(ck["filtered"].view(np.uint32), ref[:k].view(np.uint32)))
+        print("CPU_CHECK_JSON " + json.dumps({"frames": k, "filtered_equal": same,
+                                              "max_abs": float(np.abs(ref[:k]).max())}), flush=True)
     res = {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "%d frames %r float32, EMA + sigma=%g Gaussian, oracle/va_oracle.c, 1 thread of %d "
                      "usable host cores, %.1f s" % (n, frames.shape[1:], sigma, _cpu_count(), dt)}
@@ -371,11 +378,30 @@ def bench_f32(args, torch, device, dev_index, rank, world):
            "chain": {"alg_bytes_per_frame": alg, "achieved_GBs": round(alg * fps / 1e9, 1),
                      "frac_of_hbm_peak": round(alg * fps / 1e9 / HBM_PEAK_GBS, 5),
                      "stage_avg_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in stage.items()}}}
-    if not args.no_cpu_baseline:
-        res["cpu_baseline"], _ = cpu_baseline(frames[:args.cpu_frames_f32].cpu().numpy(), (sigma, rate),
-                                              "--cpu-baseline-f32-child")
+    failed = False
+    if not args.no_cpu_baseline or not args.no_check:
+        # the oracle's verdict on the first frames of the workload, from a fresh pipeline (zero state):
+        # outside the timed region, in the CPU child
+        kf = max(1, min(args.cpu_frames_f32, batch))
+        check = None
+        if not args.no_check:
+            e2 = FrameEngine(size=(w, h), channels=c, dtype=np.float32, max_batch=kf, background="ema",
+                             bg_rate=rate, sigma=sigma, device=dev_index)
+            o2 = torch.empty((kf, h, w, c), dtype=torch.float32, device=device)
+            e2.run_device(frames.data_ptr(), kf, o2.data_ptr(), None, None, None, None, stream.cuda_stream)
+            torch.cuda.synchronize(device)
+            check = {"k": np.int64(kf), "filtered": o2.cpu().numpy()}
+            e2.close()
+        cpu, chk = cpu_baseline(frames[:kf].cpu().numpy(), (sigma, rate), "--cpu-baseline-f32-child", check=check)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu
+        if check is not None:
+            res["check"] = chk if chk is not None else {"error": cpu.get("error", "the checker did not run")}
+            failed = not chk or not chk.get("filtered_equal")
     print(json.dumps(res), flush=True)
     eng.close()
+    if failed:
+        raise SystemExit("bench.py: the GPU step does not match the oracle (see \"check\")")
 
 
 def launch_ranks(args, argv):
