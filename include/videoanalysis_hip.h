@@ -359,7 +359,10 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames_dev, int n, void *filte
  * filtered_out stay ordered on the run's own stream as before.  A caller that hands consecutive runs
  * the same labels_out / stats_out buffer stays correct (the run's labelling stage then waits for the
  * previous write); alternate two buffers to overlap that stage as well.
- * va_pipeline_overlap synchronises the device; it allocates the second buffer set on first use. */
+ * va_pipeline_overlap synchronises the device; it allocates the second buffer set on first use.  The
+ * deferred write runs as a persistent kernel of 4 workgroups per CU on a lowest-priority stream (bounded
+ * footprint beside the caller's kernels); $VA_PAINT_WGS_PER_CU overrides the 4 for measurements (0: one
+ * workgroup per row block), enable == 2 gives the stream default priority. */
 int va_pipeline_overlap(va_pipeline_t *p, int enable);
 /* make `stream` wait for every label-image write this pipeline has enqueued so far (asynchronous:
  * enqueues waits, never blocks the host) */
