@@ -55,3 +55,8 @@ class VideoMemory(VideoBase):
         stop = self.frame_count if stop is None else min(stop, self.frame_count)
         for first in range(start, stop, batch_size):
             yield first, self.data[first:min(stop, first + batch_size)]
+
+
+class VideoMemoryBuffer(VideoBase):
+    """placeholder for a video that buffers another one in memory; the reference declares it without a
+    body as well (video/io/memory.py:68-71) -- the buffering role is `video.streaming.StreamedEngine` here"""
