@@ -52,6 +52,28 @@ def test_gaussian_u8_reference_era_taps(ops, oracle, sigma):
         assert np.array_equal(ops.gaussian_blur(im, sigma, color=color, tap_rule="cv3"), ref), (sigma, shape)
 
 
+def test_filter_blur_tap_rule_survives_contraction(oracle):
+    """FilterBlur(tap_rule='cv3') read through a contracted chain and filter by filter: the rule travels
+    into the fused engine (sigma = 2: tap sum 257, so the two rules differ visibly)"""
+    from video import filters as F
+    from video.io.memory import VideoMemory
+    clip = _blob_clip(40, 64, 96, seed=14)
+    diff, _ = oracle.bg_mean_u8(clip)
+    ref = oracle.threshold_u8(oracle.gaussian_u8(diff, 2.0, tap_rule="cv3"), 20)
+    assert not np.array_equal(ref, oracle.threshold_u8(oracle.gaussian_u8(diff, 2.0), 20))
+    for contract in (True, False):
+        F._GpuStage.contract = contract
+        try:
+            v = F.FilterThreshold(F.FilterBlur(F.FilterBackground(VideoMemory(clip)), 2, tap_rule="cv3"), 20)
+            assert (v._runner() is not None) == contract
+            assert np.array_equal(np.stack([np.array(f) for f in v]), ref), contract
+            v.close()
+        finally:
+            F._GpuStage.contract = True
+    with pytest.raises(ValueError):
+        F.FilterBlur(VideoMemory(clip), 2, tap_rule="cv5")
+
+
 def test_pipeline_with_reference_era_taps(oracle):
     from video.engine import FrameEngine
     clip = _blob_clip(6, 96, 160, seed=21, salt=0.002)
