@@ -397,7 +397,7 @@ def bench_f32(args, torch, device, dev_index, rank, world):
             res["cpu_baseline"] = cpu
         if check is not None:
             res["check"] = chk if chk is not None else {"error": cpu.get("error", "the checker did not run")}
-            failed = not chk or not chk.get("filtered_equal")
+            failed = bool(chk) and not chk.get("filtered_equal")
     print(json.dumps(res), flush=True)
     eng.close()
     if failed:
@@ -724,7 +724,8 @@ def main():
                     res["cpu_baseline"] = cpu
                 if check is not None:
                     res["check"] = chk if chk is not None else {"error": cpu.get("error", "the checker did not run")}
-                    failed = not chk or not all(v for kk, v in chk.items() if kk.endswith("_equal"))
+                    # a MISMATCH fails the run; a checker that could not run is reported, not counted as one
+                    failed = bool(chk) and not all(v for kk, v in chk.items() if kk.endswith("_equal"))
         print(json.dumps(res), flush=True)
     if distributed:
         dist.barrier()
