@@ -1192,7 +1192,8 @@ __device__ __forceinline__ void stats_add(int64_t *st, int y, int xs, int len)
     atomicMax(s + 13, Y);
 }
 
-template <bool STATS>
+// WORDS: mask words of a row the block keeps in LDS (64: rows up to 2048 pixels, 128: up to 4096 -- 4K)
+template <bool STATS, int WORDS = kWave>
 __global__ void __launch_bounds__(kBlock)
 ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels, int h, int w,
                  int w32, size_t total_rows, int64_t *__restrict__ stats, int max_labels,
@@ -1204,9 +1205,9 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     // multiple of 8, so that a workgroup's blocks stay on its XCD's frames) walks them with stride
     // gridDim.x -- the persistent form used when the pass runs beside other kernels
     // (va_pipeline_overlap): its footprint on a CU is then bounded by the grid, not by what is free.
-    __shared__ uint32_t s_m[kRowsPerBlock][kWave];
-    __shared__ uint32_t s_heads[kRowsPerBlock][kWave];
-    __shared__ int32_t s_lab[kRowsPerBlock][kWave][16];
+    __shared__ uint32_t s_m[kRowsPerBlock][WORDS];
+    __shared__ uint32_t s_heads[kRowsPerBlock][WORDS];
+    __shared__ int32_t s_lab[kRowsPerBlock][WORDS][16];
 
     for (int vb = blockIdx.x; vb < vblocks; vb += gridDim.x) {
     RowCtx c = row_ctx(h, total_rows, (unsigned)vb);
@@ -1245,7 +1246,19 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
     const bool use_table = md != 0;                                      // wave-uniform
     const int32_t *tf = use_table ? table + (size_t)c.f * table_stride : nullptr;
 
+    // The block's rows are contiguous in the label image.  Where the block keeps whole rows in LDS (w32 <= WORDS)
+    // and is itself whole, phase A runs for every chunk first and phase B then writes the span's 1 KiB pieces
+    // INTERLEAVED over the block's waves (wave v: pieces v, v + 4, ...; a piece may straddle two rows) instead of
+    // one row per wave: at any moment the block's stores fall into neighbouring KiB
+    // (tools/microbench/fill_rate.hip: the fewer consecutive KiB a wave streams, the closer to the fill rate).
+    // (h % 4 == 0: a block never straddles two frames and its four rows are valid or invalid together)
+#ifndef VA_PAINT_NO_INTERLEAVE
+    const bool whole = w32 <= WORDS && vec_ok && (w & 3) == 0 && (h & (kRowsPerBlock - 1)) == 0 && c.valid;
+#else
+    const bool whole = false;
+#endif
     for (int w0 = 0; w0 < w32; w0 += kWave) {
+        const int so = whole ? w0 : 0;               // where this chunk's words sit in the LDS rows
         // ---- phase A: lane <-> word; label of every run (segment) inside the word
         const int wi = w0 + c.lane;
         uint32_t m = 0, heads = 0;
@@ -1318,7 +1331,7 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                         v = L[v];  // root entry: -label, or +label if its row is already painted
                     lab = (v < 0 ? -v : v) & (kNonRootBit - 1);   // per-frame kernel: bit 30 = not a root
                 }
-                s_lab[wv][c.lane][k++] = lab;
+                s_lab[wv][so + c.lane][k++] = lab;
                 last_label = lab;
                 if (STATS && lab >= 1 && lab <= max_labels) {
                     const uint32_t seg = m >> b;
@@ -1328,55 +1341,18 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
                 }
             }
         }
-        s_m[wv][c.lane] = m;
-        s_heads[wv][c.lane] = heads;
+        s_m[wv][so + c.lane] = m;
+        s_heads[wv][so + c.lane] = heads;
         // label of the run covering the chunk's last pixel (lane 63's word, msb set)
         const int lane63_label = __shfl(last_label, kWave - 1, kWave);
         const uint32_t lane63_m = __shfl(m, kWave - 1, kWave);
+        if (whole) {                                 // (phase B follows the last chunk, below)
+            carry = (lane63_m >> 31) ? lane63_label : 0;
+            continue;
+        }
         __syncthreads();
 
         // ---- phase B: lanes write 4 consecutive pixels each, 1 KiB per wave-instruction
-#ifndef VA_PAINT_NO_INTERLEAVE
-        // The block's rows are contiguous in the label image.  Where a row is one chunk (w <= 2048) and the
-        // block is whole, its waves write the span's 1 KiB pieces INTERLEAVED (wave v: pieces v, v + 4, ...)
-        // instead of one 7.5 KiB row each: at any moment the block's stores fall into neighbouring KiB
-        // (tools/microbench/fill_rate.hip: the fewer consecutive KiB a wave streams, the closer to the fill rate).
-        // Rows of several chunks (4K: 15 KiB) keep one row per wave: sharing each row's eight pieces of a chunk
-        // out over the waves was measured and changes nothing there (0.685 vs 0.679 ms per 128 x 4K).
-        // (h % 4 == 0: a block never straddles two frames and its four rows are valid or invalid together)
-        const bool whole = w32 <= kWave && vec_ok && (w & 3) == 0 && (h & (kRowsPerBlock - 1)) == 0 && c.valid;
-        if (whole) {
-            const int y0 = c.y - wv;                                 // first row of the block
-            int32_t *span = L + (size_t)y0 * w;
-            const int span_px = kRowsPerBlock * w, pieces = (span_px + 255) >> 8;
-            for (int g = wv; g < pieces; g += kRowsPerBlock) {
-                const int off = g * 256 + c.lane * 4;
-                if (off >= span_px)
-                    continue;
-                const int r = (off >= w) + (off >= 2 * w) + (off >= 3 * w);
-                static_assert(kRowsPerBlock == 4, "row of a span offset: three comparisons");
-                const int x = off - r * w;
-                const int wl = x >> 5;
-                const uint32_t mw = s_m[r][wl], hd = s_heads[r][wl];
-                int v[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int bit = (x & 31) + j;
-                    v[j] = 0;
-                    if ((mw >> bit) & 1u) {
-                        const int k = __popc(hd & (0xFFFFFFFFu >> (31 - bit))) - 1;
-                        v[j] = s_lab[r][wl][k];
-                    }
-                }
-                typedef int v4i __attribute__((ext_vector_type(4)));
-                const v4i val = {v[0], v[1], v[2], v[3]};
-                if (kNtStores)
-                    __builtin_nontemporal_store(val, reinterpret_cast<v4i *>(span + off));
-                else
-                    *reinterpret_cast<v4i *>(span + off) = val;
-            }
-        } else
-#endif
         if (c.valid) {
             const int xbase = w0 << 5;
 #pragma unroll
@@ -1413,6 +1389,38 @@ ccl_paint_kernel(const uint32_t *__restrict__ bits, int32_t *__restrict__ labels
         carry = (lane63_m >> 31) ? lane63_label : 0;
         if (w0 + kWave < w32)          // (a barrier after the last chunk would only hold the wave until its
             __syncthreads();           // stores are acknowledged)
+    }
+    if (whole) {
+        __syncthreads();
+        const int y0 = c.y - wv;                                 // first row of the block
+        int32_t *span = L + (size_t)y0 * w;
+        const int span_px = kRowsPerBlock * w, pieces = (span_px + 255) >> 8;
+        for (int g = wv; g < pieces; g += kRowsPerBlock) {
+            const int off = g * 256 + c.lane * 4;
+            if (off >= span_px)
+                continue;
+            const int r = (off >= w) + (off >= 2 * w) + (off >= 3 * w);
+            static_assert(kRowsPerBlock == 4, "row of a span offset: three comparisons");
+            const int x = off - r * w;
+            const int wl = x >> 5;
+            const uint32_t mw = s_m[r][wl], hd = s_heads[r][wl];
+            int v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int bit = (x & 31) + j;
+                v[j] = 0;
+                if ((mw >> bit) & 1u) {
+                    const int k = __popc(hd & (0xFFFFFFFFu >> (31 - bit))) - 1;
+                    v[j] = s_lab[r][wl][k];
+                }
+            }
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i val = {v[0], v[1], v[2], v[3]};
+            if (kNtStores)
+                __builtin_nontemporal_store(val, reinterpret_cast<v4i *>(span + off));
+            else
+                *reinterpret_cast<v4i *>(span + off) = val;
+        }
     }
     // (persistent form: the interleaved phase B reads the other waves' LDS slices, so the next row block's
     //  phase A must not start before every wave is through)
@@ -1861,20 +1869,30 @@ int launch_ccl_paint(const CclPaintPlan &pl, hipStream_t st, StageProfiler *prof
     const int grid = cdiv((long long)total_rows, kRowsPerBlock);          // paint: wave = row
     const int vblocks = pl.xcd_frames ? 8 * pl.xcd_frames * cdiv(n, 8) : grid;
     const int pgrid = pl.persistent_grid > 0 ? min(vblocks, pl.persistent_grid) : vblocks;
+    // rows of 65 ... 128 mask words (4K) keep whole rows in LDS as well: 36 KB per block, 4 blocks per CU -- the
+    // pass runs as fast at that occupancy (measured with a padded 1080p build)
+    const bool wide = w32 > kWave && w32 <= 2 * kWave && vec && (w & 3) == 0 && (h & (kRowsPerBlock - 1)) == 0;
+#define VA_PAINT_LAUNCH(ST, WORDS, STATSP, ML)                                                                      \
+    ccl_paint_kernel<ST, WORDS><<<pgrid, kBlock, 0, st>>>(pl.bits, pl.labels, h, w, w32, total_rows, STATSP, ML, vec, \
+                                                        pl.run_table, pl.table_stride, pl.row_off, pl.frame_mode,    \
+                                                        pl.xcd_frames, vblocks)
     if (pl.stats && pl.max_labels > 0) {
         size_t entries = (size_t)n * pl.max_labels;
         stats_init_kernel<<<cdiv((long long)entries * VA_STATS_STRIDE, kBlock), kBlock, 0, st>>>(
             pl.stats, entries, h, w);
         VA_LAUNCH_CHECK("stats_init_kernel");
         VA_MARK("stats_init");
-        ccl_paint_kernel<true><<<pgrid, kBlock, 0, st>>>(pl.bits, pl.labels, h, w, w32, total_rows, pl.stats,
-                                                        pl.max_labels, vec, pl.run_table, pl.table_stride,
-                                                        pl.row_off, pl.frame_mode, pl.xcd_frames, vblocks);
+        if (wide)
+            VA_PAINT_LAUNCH(true, 2 * kWave, pl.stats, pl.max_labels);
+        else
+            VA_PAINT_LAUNCH(true, kWave, pl.stats, pl.max_labels);
     } else {
-        ccl_paint_kernel<false><<<pgrid, kBlock, 0, st>>>(pl.bits, pl.labels, h, w, w32, total_rows, nullptr, 0,
-                                                         vec, pl.run_table, pl.table_stride, pl.row_off,
-                                                         pl.frame_mode, pl.xcd_frames, vblocks);
+        if (wide)
+            VA_PAINT_LAUNCH(false, 2 * kWave, nullptr, 0);
+        else
+            VA_PAINT_LAUNCH(false, kWave, nullptr, 0);
     }
+#undef VA_PAINT_LAUNCH
     VA_LAUNCH_CHECK("ccl_paint_kernel");
     VA_MARK("ccl_paint");
 #undef VA_MARK
