@@ -614,7 +614,10 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    eng.profile(True)
+    # per-stage HIP events inside the timed region, on every 4th step (an event per stage on every step costs
+    # about 2 % of the chain: tools/debug/profile_overhead.py); fewer than 8 steps: every step
+    sample = 4 if args.steps >= 8 else 1
+    eng.profile(True, every=sample)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record(stream)
@@ -681,7 +684,9 @@ def main():
             "chain": {"alg_bytes_per_frame": chain_bytes_per_frame,
                       "achieved_GBs": round(chain_bytes_per_frame * fps / world / 1e9, 2),
                       "frac_of_hbm_peak_per_gpu": round(chain_bytes_per_frame * fps / world / 1e9 / HBM_PEAK_GBS, 5),
-                      "stage_avg_ms": stage_ms},
+                      "stage_avg_ms": stage_ms,
+                      "stage_events": "HIP events on the launch stream, every %s step of the timed region (%d launches)"
+                                      % ("4th" if sample == 4 else "", max(v[1] for v in stage.values()) if stage else 0)},
         }
         if world == 1:
             # ---- everything below is outside the timed region ------------------------------------

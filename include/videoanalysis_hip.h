@@ -376,7 +376,8 @@ const char *va_pipeline_describe(const va_pipeline_t *p);
 
 /* per-stage device time, measured with HIP events recorded on the run's own stream (what
  * bench.py's `roofline` object is computed from).  enable != 0 starts/reset recording; every
- * va_pipeline_run then records one event per stage (never waits).  stage_times waits for the
+ * va_pipeline_run (enable > 1: every enable-th run, the first one included -- an event per stage costs
+ * the stream about 2 % of the chain) then records one event per stage (never waits).  stage_times waits for the
  * last event and sums, per stage name, the elapsed ms and the number of launches.
  * names: capacity x 32 chars. */
 int va_pipeline_profile(va_pipeline_t *p, int enable);

@@ -1203,7 +1203,7 @@ int va_pipeline_run(va_pipeline_t *p, const void *frames, int n, void *filtered_
     const size_t esz = c.dtype == VA_U8 ? 1 : 4;
     int rc;
     const void *cur = frames;
-    StageProfiler *prof = (p->prof && p->prof->enabled) ? p->prof : nullptr;
+    StageProfiler *prof = (p->prof && p->prof->enabled && p->prof->runs++ % p->prof->every == 0) ? p->prof : nullptr;
 #define VA_MARK(nm)             \
     do {                        \
         if (prof)               \
@@ -1405,6 +1405,8 @@ int va_pipeline_profile(va_pipeline_t *p, int enable)
         }
     }
     p->prof->enabled = enable != 0;
+    p->prof->every = enable > 1 ? enable : 1;
+    p->prof->runs = 0;
     p->prof->n = 0;
     p->prof->dropped = 0;
     return VA_OK;

@@ -52,6 +52,7 @@ constexpr size_t kMaxFramePixels = (size_t)1 << 29;
 struct StageProfiler {
     static constexpr int kMaxMarks = 4096;
     bool enabled = false;
+    int every = 1, runs = 0;     // events go into every `every`-th run (an event per stage costs the stream ~2 %)
     int n = 0, dropped = 0;
     hipEvent_t ev[kMaxMarks];
     const char *name[kMaxMarks];  // nullptr = start of a run
