@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Phase ablation of the fused float32 kernels (va_gauss_f32_fused.hip) on an MI355X.
+"""(round-2 tool, kept for reference: its embedded launches predate the round-3 kernel signatures; ablation builds are
+made with tools/debug/build_variant.sh now)
+
+Phase ablation of the fused float32 kernels (va_gauss_f32_fused.hip) on an MI355X.
 
 Builds variants of the PRODUCT source by textual substitution (nothing here ships), times
 ema_row_f32_kernel<3,true> and col_march_f32_kernel on 64 x 1080p x 3 float32 frames and prints
