@@ -1223,6 +1223,15 @@ def test_resize_f32_matches_oracle(ops, oracle, mode):
     assert np.array_equal(ops.resize(img, (120, 90), mode), img)
 
 
+def test_resize_more_frames_than_one_grid_dimension(ops, oracle):
+    """more than 65535 frames in one call: the launch goes out in pieces of gridDim.z frames"""
+    rng = np.random.default_rng(2)
+    tiny = rng.integers(0, 256, (65540, 4, 6), dtype=np.uint8)
+    got = ops.resize(tiny, (3, 2), "linear")
+    ref = oracle.resize_u8(tiny, (3, 2), "linear")
+    assert got.shape == (65540, 2, 3) and np.array_equal(got, ref)
+
+
 def test_filter_resize_plumbing(ops, oracle):
     from video.filters import FilterResize
     from video.io.memory import VideoMemory
