@@ -133,7 +133,8 @@ def test_resize_vs_cv2(ops):
     rng = np.random.default_rng(12)
     img = rng.integers(0, 256, (90, 120), dtype=np.uint8)
     col = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
-    modes = {"nearest": cv2.INTER_NEAREST, "linear": cv2.INTER_LINEAR, "area": cv2.INTER_AREA}
+    modes = {"nearest": cv2.INTER_NEAREST, "linear": cv2.INTER_LINEAR, "area": cv2.INTER_AREA,
+             "cubic": cv2.INTER_CUBIC, "lanczos": cv2.INTER_LANCZOS4}
     if not hasattr(ops, "resize"):
         pytest.skip("resize not built")
     for name, code in modes.items():
@@ -144,3 +145,31 @@ def test_resize_vs_cv2(ops):
                 d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
                 print("[cv2 parity] resize %s %r -> %r: max |diff| %d" % (name, im.shape, size, d.max()))
                 assert d.max() <= (0 if name == "nearest" else 1)
+
+
+def test_resize_f32_vs_cv2(ops):
+    """float32 frames: the <float, float, float> instantiations; OpenCV's SIMD paths may contract or
+    reorder the sums, so the bar is a few ULP, printed"""
+    rng = np.random.default_rng(13)
+    img = rng.normal(0.5, 0.3, (90, 120)).astype(np.float32)
+    modes = {"nearest": cv2.INTER_NEAREST, "linear": cv2.INTER_LINEAR, "area": cv2.INTER_AREA,
+             "cubic": cv2.INTER_CUBIC, "lanczos": cv2.INTER_LANCZOS4}
+    for name, code in modes.items():
+        for size in ((60, 45), (40, 30), (240, 180), (77, 51)):
+            ref = cv2.resize(img, size, interpolation=code)
+            got = ops.resize(img, size, name)
+            err = float(np.abs(got - ref).max())
+            print("[cv2 parity] resize float32 %s -> %r: max |diff| %.3g" % (name, size, err))
+            assert err <= (0 if name == "nearest" else 2e-6 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_peaks_and_temporal_statistics_vs_numpy_literal(ops):
+    """not cv2, but the same spirit: measure_mean on float32 / int16 frames against the literal NumPy loop
+    of the reference (video/analysis/video.py:30-33) executed right here"""
+    rng = np.random.default_rng(14)
+    for dtype in (np.float32, np.int16):
+        frames = (rng.normal(0, 50, (9, 12, 15))).astype(dtype)
+        mean = np.zeros(frames.shape[1:])
+        for n, frame in enumerate(frames):
+            mean = mean * n / (n + 1) + frame / (n + 1)
+        assert np.array_equal(ops.running_mean(frames), mean), dtype
