@@ -40,7 +40,10 @@ WORKLOADS = {
     "cfg1_480p_small": (640, 480, 64, 2.0, 20, 0, 3, 0.0),
 }
 # BASELINE.json configs[4]: float32 3-channel frames, adaptive (EMA) background + sigma=9 blur
-F32_WORKLOADS = {"cfg5_1080p_f32x3_sigma9": (1920, 1080, 3, 256, 9.0, 0.02)}
+F32_WORKLOADS = {"cfg5_1080p_f32x3_sigma9": (1920, 1080, 3, 256, 9.0, 0.02),
+                 # probe, not a BASELINE config: mono frames with cfg#5's samples per row and per frame -- what
+                 # the row pass costs without the channel interleave
+                 "probe_5760x1080_f32x1_sigma9": (5760, 1080, 1, 256, 9.0, 0.02)}
 
 # algorithmic (compulsory) bytes per frame-pixel of each stage = every input byte of the stage
 # read once + every output byte written once (DESIGN.md "Kernels"); bits = 1/8 B per pixel

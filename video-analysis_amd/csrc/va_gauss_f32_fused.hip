@@ -526,6 +526,40 @@ ema_row_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, co
 //     sub-chunk's next frame is requested as soon as its current one is staged -- two phases ahead.
 namespace is {
 
+// -DROWIS_STAMPS=1 | 2 | 3 (debug builds only, tools/debug/rowis_stamps.py): cycles every loader wave (1) and / or
+// every compute wave (2) of one workgroup spends in each barrier and in each part of a phase, summed over the
+// launch.  Scalar registers only (s_memtime, 32-bit sums): the kernel has no vector register to spare.
+#ifdef ROWIS_STAMPS
+__device__ unsigned int g_rowis_stamps[16][8];   // [wave][barrier A, B, C, part 1, part 2, part 3, -, total]
+__device__ __forceinline__ unsigned rowis_now()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return (unsigned)t;
+}
+#define ROWIS_T0_() const unsigned t0_ = rowis_now()
+#define ROWIS_ACC_(idx) stamp_acc##idx += rowis_now() - t0_
+#define ROWIS_BARRIER_(idx) do { ROWIS_T0_(); lds_barrier(); ROWIS_ACC_(idx); } while (0)
+#endif
+#if defined(ROWIS_STAMPS) && (ROWIS_STAMPS & 1)
+#define LSTAMP_T0() ROWIS_T0_()
+#define LSTAMP_ACC(idx) ROWIS_ACC_(idx)
+#define LSTAMP_BARRIER(idx) ROWIS_BARRIER_(idx)
+#else
+#define LSTAMP_T0() do { } while (0)
+#define LSTAMP_ACC(idx) do { } while (0)
+#define LSTAMP_BARRIER(idx) lds_barrier()
+#endif
+#if defined(ROWIS_STAMPS) && (ROWIS_STAMPS & 2)
+#define CSTAMP_T0() ROWIS_T0_()
+#define CSTAMP_ACC(idx) ROWIS_ACC_(idx)
+#define CSTAMP_BARRIER(idx) ROWIS_BARRIER_(idx)
+#else
+#define CSTAMP_T0() do { } while (0)
+#define CSTAMP_ACC(idx) do { } while (0)
+#define CSTAMP_BARRIER(idx) lds_barrier()
+#endif
+
 #ifndef ROWIS_CPOS
 #define ROWIS_CPOS 4         // barrier C sits at ROWIS_CPOS / 8 of the compute waves' row pass
 #endif
@@ -589,7 +623,7 @@ inline bool fits(long long L, int rw, int halo, int p2)
            (L + 2 * halo + 8 + 3) / 4 <= (long long)kNS * kTW;
 }
 
-template <int C, int RAD, int kP2>
+template <int C, int RAD, int kP2, bool EMA>
 __global__ void __launch_bounds__(kTW + kTC)   // (HALO = RAD C <= 108 < kTW)
 row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, const float *__restrict__ bg,
                   float *__restrict__ bg_out, long long n_seen, float rate, int nframes, int h, int w, int L,
@@ -605,8 +639,9 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
     // per staging, each behind the compute waves' own LDS traffic)
     static_assert(kNS <= 8, "the staging map of a thread is one 16-byte LDS read");
     __shared__ __attribute__((aligned(16))) unsigned short smap[2][kTW][8];
+    __shared__ __attribute__((aligned(16))) unsigned short cmap[2][kTW][8];   // copy-out: O index / 4 of a thread's slots
 
-    const bool ema = bg != nullptr;                  // uniform
+    constexpr bool ema = EMA;                        // (a run-time flag cost eight v_cndmask per staged float4)
     const int rw = w * C, total = h * rw;
     const size_t fstride = (size_t)total;
     const int f0 = ema ? 0 : blockIdx.y, f1 = ema ? nframes : blockIdx.y + 1;
@@ -619,6 +654,10 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
         for (int k = 0; k < (int)(blockIdx.x & 7); k++)
             __builtin_amdgcn_s_sleep(127);
     const bool loader = threadIdx.x < kTW;           // wave-uniform
+#ifdef ROWIS_STAMPS
+    unsigned stamp_acc0 = 0, stamp_acc1 = 0, stamp_acc2 = 0, stamp_acc3 = 0, stamp_acc4 = 0, stamp_acc5 = 0;
+    const unsigned stamp_start = rowis_now();
+#endif
     const int tid = loader ? threadIdx.x : threadIdx.x - kTW;
     const Tab T0 = make_tab((2 * blockIdx.x) * L, L, total, h, rw, HALO);
     const Tab T1 = make_tab((2 * blockIdx.x + 1) * L, L, total, h, rw, HALO);
@@ -626,38 +665,34 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
     // results of a phase leave as 16-byte pieces: output float4 fo of piece k sits at
     // O[fo - rs[k] + D[k] - HALO] (O = the buffer itself, indexed by window start).  Loader waves only:
     // a store blocks its wave for as long as the memory system takes to accept it, and the compute waves
-    // have the next row pass to run meanwhile.
-    auto copy_out = [&](const Tab &T, const float *O, int f) {
-        char *out = reinterpret_cast<char *>(tmp + (size_t)f * fstride);
-        int fo0 = T.cs + 4 * tid;
-        asm volatile("" : "+v"(fo0));
-        const int nsl = (T.ce - T.cs + 4 * kTW - 1) / (4 * kTW);        // uniform
-        // the LDS read of slot m + 1 is in flight while slot m's store waits to be accepted
-        auto fetch = [&](int m) {
-            const int fo = fo0 + 4 * kTW * m;
-            f4 v = f4{0.f, 0.f, 0.f, 0.f};
-            if (fo < T.ce) {
-                int p = fo - T.rs[0] + T.D[0];
-#pragma unroll
-                for (int k = 1; k < kSeg; k++)
-                    if (T.qa[k] < T.qb[k] && fo >= T.rs[k])
-                        p = fo - T.rs[k] + T.D[k];
-                v = *reinterpret_cast<const f4 *>(O + (p - HALO));
-            }
-            return v;
-        };
+    // have the next row pass to run meanwhile.  Where slot m of a thread (the float4 at flat index
+    // cs + 4 (tid + kTW m)) sits in O is the same for every frame: looked up once (cmap, one 16-byte LDS read
+    // per copy-out); slots past the chunk end are dropped by the buffer store's own range check, so the loop has
+    // no per-lane branch and no address arithmetic (it had 18 vector instructions per slot).
+    auto copy_out = [&](int sub, const Tab &T, const float *O, int f) {
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const u4v cm = *reinterpret_cast<const u4v *>(&cmap[sub][t][0]);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tmp + (size_t)f * fstride, 0, T.ce * 4, 0x00027000);
+        int ob = 4 * (T.cs + 4 * tid);
+        asm volatile("" : "+v"(ob));
+        const f4 *O4 = reinterpret_cast<const f4 *>(O);
+        auto fetch = [&](int m) { return O4[(cm[m >> 1] >> (16 * (m & 1))) & 0xFFFFu]; };
+        // Always kNS stores (those past the chunk end are dropped by the range check): a store count that depends
+        // on a branch makes the compiler wait for ALL stores of the copy-out -- their acknowledgements, a memory
+        // round trip -- before the next staging may use the frame loads issued ahead of them (vmcnt counts both).
+        // The LDS read of slot m + 1 is in flight while slot m's store waits to be accepted.
         f4 nxt = fetch(0);
-        for (int m = 0; m < nsl; m++) {
-            const int fo = fo0 + 4 * kTW * m;
+#pragma unroll
+        for (int m = 0; m < kNS; m++) {
             const f4 v = nxt;
-            if (m + 1 < nsl)
+            if (m + 1 < kNS)
                 nxt = fetch(m + 1);
-            if (fo < T.ce) {
 #ifdef ROWIS_NO_STORE
-                if (v.x == 123.456f)
+            if (v.x == 123.456f)
 #endif
-                __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (unsigned)(4 * fo)));
-            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rsrc, ob, 16 * kTW * m, 2 /* nt */);
         }
     };
 
@@ -680,6 +715,21 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
                     }
                 }
                 smap[sub][tid][m] = (unsigned short)info;
+                // copy-out slot m: output float4 fo of piece k sits at O[fo - rs[k] + D[k] - HALO]
+                const int fo = T.cs + 4 * tid + 4 * kTW * m;
+                int p = HALO;
+                if (fo < T.ce) {
+                    p = fo - T.rs[0] + T.D[0];
+#pragma unroll
+                    for (int k = 1; k < kSeg; k++)
+                        if (T.qa[k] < T.qb[k] && fo >= T.rs[k])
+                            p = fo - T.rs[k] + T.D[k];
+                }
+                cmap[sub][tid][m] = (unsigned short)((p - HALO) >> 2);
+            }
+            if (kNS < 8) {
+                smap[sub][tid][7] = 0;
+                cmap[sub][tid][7] = 0;
             }
         };
         make_map(T0, 0);
@@ -721,13 +771,18 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
             asm volatile("" : "+v"(t));
             typedef unsigned int u4v __attribute__((ext_vector_type(4)));
             const u4v map = *reinterpret_cast<const u4v *>(&smap[sub][t][0]);
+            if (first) {                                 // (uniform; the very first frame only) bg = the frame itself
+#pragma unroll
+                for (int m = 0; m < kNS; m++)
+                    st[m] = ld[m];
+            }
 #pragma unroll
             for (int m = 0; m < kNS; m++) {
                 const int info = (int)((map[m >> 1] >> (16 * (m & 1))) & 0xFFFFu);
                 if (info != 0) {
                     f4 v = ld[m];
                     if (ema) {
-                        f4 s = first ? v : st[m];
+                        const f4 s = st[m];
                         const f4 d = v - s;                              // oracle order: d = x - bg
                         const f4 step = f4{rate, rate, rate, rate} * d;  // step = rate * d (no contraction)
                         st[m] = s + step;                                // bg = bg + step
@@ -768,26 +823,45 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
         lds_barrier();
         fixup(T0, Xs[0]);
         lds_barrier();
+        {
+            // kNS stores that the range check drops (a buffer of no bytes): the loop is then entered the way its
+            // back edge arrives -- a sub-chunk's loads, then kNS stores -- and the staging at its top waits for
+            // the loads only (vmcnt(2 kNS - 1 - m)); entered with the loads alone outstanding, the compiler had to
+            // assume vmcnt(kNS - 1 - m), which on every later pass waited for the previous copy-out's stores as well
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(tmp, 0, 0, 0x00027000);
+#pragma unroll
+            for (int m = 0; m < kNS; m++)
+                __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, none, 0, 16 * m, 0);
+        }
         lds_barrier();                                                  // (the C of the compute waves' first row pass)
         for (int f = f0; f < f1; f++) {
             // ---- the compute waves filter buffer 0 (sub-chunk 0 of frame f)
-            stage(1, Xs[1], st1, ema && (n_seen + f) == 0);
-            issue_loads(T0, f + 1);
-            lds_barrier();                                              // A: row pass done, staging done
-            fixup(T1, Xs[1]);
-            lds_barrier();                                              // B: O written, buffer 1 complete
-            copy_out(T0, Xs[0], f);                                     // (the compute waves are in buffer 1)
+            { LSTAMP_T0(); stage(1, Xs[1], st1, ema && (n_seen + f) == 0);
+            issue_loads(T0, f + 1); LSTAMP_ACC(3); }
+            LSTAMP_BARRIER(0);                                           // A: row pass done, staging done
+            { LSTAMP_T0(); fixup(T1, Xs[1]); LSTAMP_ACC(4); }
+            LSTAMP_BARRIER(1);                                           // B: O written, buffer 1 complete
+            { LSTAMP_T0(); copy_out(0, T0, Xs[0], f); LSTAMP_ACC(5); }    // (the compute waves are in buffer 1)
             // ---- buffer 1 (sub-chunk 1 of frame f)
-            lds_barrier();                                              // C: every loader wave has copied buffer 0 out
+            LSTAMP_BARRIER(2);                                           // C: every loader wave has copied buffer 0 out
+            { LSTAMP_T0();
             if (f + 1 < f1)                                             //    (the compute waves pass C half-way through
                 stage(0, Xs[0], st0, false);                            //    their row pass; the state must not see a frame twice)
-            issue_loads(T1, f + 1);
-            lds_barrier();
-            fixup(T0, Xs[0]);
-            lds_barrier();
-            copy_out(T1, Xs[1], f);
-            lds_barrier();                                              // C: buffer 1 copied out before it is staged again
+            issue_loads(T1, f + 1); LSTAMP_ACC(3); }
+            LSTAMP_BARRIER(0);
+            { LSTAMP_T0(); fixup(T0, Xs[0]); LSTAMP_ACC(4); }
+            LSTAMP_BARRIER(1);
+            { LSTAMP_T0(); copy_out(1, T1, Xs[1], f); LSTAMP_ACC(5); }
+            LSTAMP_BARRIER(2);                                           // C: buffer 1 copied out before it is staged again
         }
+#if defined(ROWIS_STAMPS) && (ROWIS_STAMPS & 1)
+        if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) {
+            unsigned *o = g_rowis_stamps[threadIdx.x >> 6];
+            o[0] = stamp_acc0, o[1] = stamp_acc1, o[2] = stamp_acc2, o[3] = stamp_acc3, o[4] = stamp_acc4;
+            o[5] = stamp_acc5, o[7] = rowis_now() - stamp_start;
+        }
+#endif
         if (ema) {
             // into a SECOND buffer: a neighbouring workgroup that starts late reads the halo of its chunk
             // -- samples this workgroup owns -- from `bg`, which must still hold the state before the batch
@@ -810,8 +884,17 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
     // two halves of a packed operand (v_pk_fma_f32: plain v_fma_f32 has HALF the flop rate), read from LDS
     // with one ds_read2st64_b32.  The taps are scalar operands; the set is symmetric (checked on the host),
     // so RAD + 1 scalar registers do (2 RAD + 1 spill, and every use of a spilled one is a v_readlane).
+    // a compute thread's index is rebuilt from the lane id where it is needed: every register is in use, and
+    // kept across the row pass it was spilled -- two scratch reloads (a memory round trip each, the second one
+    // between barriers A and B with the loader waves waiting) per phase
+    const int cwave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x - kTW) >> 6);
+    auto compute_tid = [&]() {
+        int lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        return (cwave << 6) | lane;
+    };
     auto row_pass = [&](const float *X, f2 (&acc)[kP2]) {
-        int off = kP2 * tid;
+        int off = kP2 * compute_tid();
         asm volatile("" : "+v"(off));
         const float *xb = X + off;
 #pragma unroll
@@ -833,7 +916,7 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
             // barrier C of the loader waves (the buffer they copied out may be staged again): passed here,
             // half-way, so that neither side waits for long
             if (i == kInputsRun * ROWIS_CPOS / 8)
-                lds_barrier();
+                CSTAMP_BARRIER(2);
             const f2 x = xs[i % kAhead];
             if (i + kAhead < NIN)
                 xs[i % kAhead] = f2{xb[i + kAhead], xb[kHoff + i + kAhead]};
@@ -850,7 +933,7 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
         }
     };
     auto write_O = [&](float *O, const f2 (&acc)[kP2]) {
-        int off = kP2 * tid;
+        int off = kP2 * compute_tid();
         asm volatile("" : "+v"(off));
 #pragma unroll
         for (int j = 0; j < kP2; j++) {
@@ -864,12 +947,19 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
     for (int q = 0; q < Q; q++) {                    // (one copy of the unrolled row pass for both buffers)
         float *X = Xs[q & 1];
         f2 acc[kP2];
-        row_pass(X, acc);                            // (barrier C of the previous phase's copy-out inside)
-        lds_barrier();                                                  // A
-        write_O(X, acc);
-        lds_barrier();                                                  // B
+        { CSTAMP_T0(); row_pass(X, acc); CSTAMP_ACC(3); }   // (barrier C of the previous phase's copy-out inside)
+        CSTAMP_BARRIER(0);                                              // A
+        { CSTAMP_T0(); write_O(X, acc); CSTAMP_ACC(4); }
+        CSTAMP_BARRIER(1);                                              // B
     }
     lds_barrier();                                                      // (the C after the last copy-out)
+#if defined(ROWIS_STAMPS) && (ROWIS_STAMPS & 2)
+    if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) {
+        unsigned *o = g_rowis_stamps[threadIdx.x >> 6];
+        o[0] = stamp_acc0, o[1] = stamp_acc1, o[2] = stamp_acc2, o[3] = stamp_acc3, o[4] = stamp_acc4;
+        o[7] = rowis_now() - stamp_start;
+    }
+#endif
 }
 
 }  // namespace is
@@ -1398,7 +1488,10 @@ static bool launch_row_is(int r, unsigned nwg, unsigned ny, const float *src, fl
     const dim3 grid(nwg, ny);
 #define VA_ROW_IS(RAD)                                                                                        \
     case RAD:                                                                                                 \
-        is::row_is_f32_kernel<C, RAD, P2><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, bg_out, n_seen, rate, n, h, w, L, taps); \
+        if (bg)                                                                                               \
+            is::row_is_f32_kernel<C, RAD, P2, true><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, bg_out, n_seen, rate, n, h, w, L, taps); \
+        else                                                                                                  \
+            is::row_is_f32_kernel<C, RAD, P2, false><<<grid, is::kTW + is::kTC, 0, st>>>(src, tmp, bg, bg_out, n_seen, rate, n, h, w, L, taps); \
         return true;
     switch (r) {
         VA_ROW_IS(4) VA_ROW_IS(8) VA_ROW_IS(12) VA_ROW_IS(16) VA_ROW_IS(20) VA_ROW_IS(24) VA_ROW_IS(28) VA_ROW_IS(32)
@@ -1496,5 +1589,12 @@ int launch_gauss_f32_fused(const float *src, float *dst, float *scratch, const f
         prof->mark("col_f32", st);
     return VA_OK;
 }
+
+#ifdef ROWIS_STAMPS
+extern "C" int va_debug_rowis_stamps(unsigned int *out32)
+{
+    return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(is::g_rowis_stamps), 128 * sizeof(unsigned int));
+}
+#endif
 
 }  // namespace va
