@@ -150,6 +150,30 @@ def test_mask_only_chain_writes_bytes_from_the_gaussian(oracle, shape, sigma, th
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("shape,sigma,thresh", [((3, 97, 208), 6.0, 20), ((2, 64, 64), 8.0, 100),
+                                                ((1, 200, 528), 10.0, 60), ((2, 70, 1936), 9.0, 127)])
+def test_wide_sigma_chain_stays_on_the_single_launch_gaussian(oracle, shape, sigma, thresh):
+    """sigma beyond the matrix-core kernel's radius 16: the chain keeps a single-launch Gaussian (dot4/dot2 with a
+    32-column halo) that thresholds in its epilogue -- mask, blur and labels against the oracle"""
+    rng = np.random.default_rng(shape[2] + thresh)
+    clip = rng.integers(0, 256, shape, dtype=np.uint8)
+    clip[0, :9, :] = 255
+    clip[-1, :, -40:] = 0
+    eng = _engine(size=(shape[2], shape[1]), max_batch=shape[0], sigma=sigma, thresh=thresh, connectivity=4,
+                  max_labels=4096)
+    assert "fused" in eng.description, eng.description
+    out = eng.run(clip, want=("mask", "filtered", "labels", "counts"))
+    eng.close()
+    blur = oracle.gaussian_u8(clip, sigma)
+    ref = oracle.threshold_u8(blur, thresh, 255)
+    assert np.array_equal(out["filtered"], blur)
+    assert np.array_equal(out["mask"], ref)
+    for f in range(shape[0]):
+        lab, cnt = oracle.label(ref[f], 4)
+        assert cnt == out["counts"][f]
+        assert np.array_equal(lab, out["labels"][f])
+
+
 def test_cfg4_4k_full_chain_both_labelling_paths(oracle):
     """BASELINE.json configs[3]: 3840x2160 uint8 full chain; one rank's shard of the 1024-frame
     batch (128 frames) through va_pipeline_run, with the library's labelling choice (per-frame

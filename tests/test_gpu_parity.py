@@ -135,6 +135,29 @@ def test_gaussian_u8_single_launch_kernels(ops, oracle, shape, sigma):
         assert np.array_equal(ops.gaussian_blur(c, sigma), c)
 
 
+@pytest.mark.parametrize("shape,sigma", [((2, 64, 64), 5.5), ((1, 100, 208), 6.0), ((2, 77, 128), 7.0),
+                                         ((1, 65, 1936), 8.0), ((1, 130, 336), 8.3), ((2, 96, 192), 10.0),
+                                         ((1, 64, 400), 10.7), ((1, 1080, 256), 9.0)])
+def test_gaussian_u8_wide_radius_kernels(ops, oracle, shape, sigma):
+    """radii 17 ... 32 (sigma up to 10.7): the dot4/dot2 kernel with a 32-column halo (two mirrored vectors per
+    row end, up to 32 mirrored rows) -- the library's choice there, since the matrix-core kernel stops at
+    radius 16 -- against the oracle and the generic two-pass kernels"""
+    assert 16 < len(oracle.gauss_taps_q8(sigma)) // 2 <= 32
+    rng = np.random.default_rng(shape[2] + int(sigma * 10))
+    im = rng.integers(0, 256, shape, dtype=np.uint8)
+    im[0, :8, :] = 255
+    im[0, -8:, :] = 0
+    im[-1, :, :40] = 255
+    im[-1, :, -40:] = 255
+    ref = oracle.gaussian_u8(im, sigma)
+    assert np.array_equal(ops.gaussian_blur(im, sigma), ref)
+    assert np.array_equal(ops.gaussian_blur(im, sigma, implementation="valu"), ref)
+    assert np.array_equal(ops.gaussian_blur(im, sigma, implementation="generic"), ref)
+    for v in (0, 255):
+        c = np.full(shape, v, np.uint8)
+        assert np.array_equal(ops.gaussian_blur(c, sigma), c)
+
+
 @pytest.mark.parametrize("shape,sigma", [((2, 48, 64, 3), 2.0), ((1, 33, 112, 3), 5.0), ((3, 40, 80, 2), 1.0),
                                          ((1, 64, 96, 4), 3.3), ((1, 35, 1936, 3), 4.0),
                                          ((2, 40, 67), 5.3), ((1, 33, 1918), 5.0), ((2, 50, 101, 3), 2.0),

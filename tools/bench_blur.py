@@ -11,8 +11,8 @@ n,h,w=256,1080,1920
 src=torch.randint(0,256,(n,h,w),dtype=torch.uint8,device="cuda")
 dst=torch.empty_like(src)
 st=torch.cuda.current_stream().cuda_stream
-for name,fn in (("mfma",L.va_gaussian_u8),("valu",L.va_gaussian_u8_valu),("generic",L.va_gaussian_u8_generic)):
-    for sigma in (5.0, 2.0):
+for name,fn in (("default",L.va_gaussian_u8),("valu",L.va_gaussian_u8_valu),("generic",L.va_gaussian_u8_generic)):
+    for sigma in (5.0, 2.0, 8.0, 10.0):     # (radius <= 16: "default" = matrix cores; 17 ... 32: the wide dot4/dot2 kernel)
         for _ in range(2): _hip.check(fn(src.data_ptr(),dst.data_ptr(),n,h,w,1,C.c_double(sigma),st))
         torch.cuda.synchronize(); t0=time.perf_counter()
         for _ in range(5): _hip.check(fn(src.data_ptr(),dst.data_ptr(),n,h,w,1,C.c_double(sigma),st))

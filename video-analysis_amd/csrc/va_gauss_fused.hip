@@ -50,21 +50,26 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return min(max(p, 0), len - 1);
 }
 
-constexpr int kHalo = 16;   // staged columns left and right of the strip (>= padded radius)
+// staged columns left and right of the strip (>= padded radius): 16 for radii up to 16, 32 for the wide kernels
+// (sigma up to 10.5: radius 17 ... 32)
+constexpr int kMaxHalo = 32;
 constexpr int kRowsPerStep = 16;   // 16 vs 8 rows per step: -1.5 % time (fixed costs amortised)
 
+template <int HALO>
 struct FusedWeights {
-    uint32_t wrow[4][9];  // byte weights for output o = 0..3 over the thread's 36-byte window
-    uint32_t we[17];      // (tap[2j], tap[2j+1]) pairs for even output rows
-    uint32_t wo[17];      // (tap[2j-1], tap[2j]) pairs for odd output rows
+    uint32_t wrow[4][HALO / 2 + 1];  // byte weights for output o = 0..3 over the thread's (4 + 2 HALO)-byte window
+    uint32_t we[HALO + 1];           // (tap[2j], tap[2j+1]) pairs for even output rows
+    uint32_t wo[HALO + 1];           // (tap[2j-1], tap[2j]) pairs for odd output rows
 };
 
 template <int TW, int RP, int ROWS, bool HAS_DST, bool HAS_BITS>
 __global__ void __launch_bounds__(TW)
 gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                    uint32_t *__restrict__ bits, int thresh, int h, int w, int w32, int nstrips,
-                   FusedWeights wt)
+                   FusedWeights<(RP <= 16 ? 16 : 32)> wt)
 {
+    constexpr int kHalo = RP <= 16 ? 16 : 32;
+    constexpr int WD = kHalo / 2 + 1;        // dwords of a row-pass window
     constexpr int IW = TW + 2 * kHalo;       // staged bytes per input row
     constexpr int IWD = IW / 4;
     constexpr int PPS = ROWS / 2;            // packed pair-rows produced per step
@@ -77,7 +82,7 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     constexpr int UPR = TW / 4;              // row-pass units (4 pixels x 2 rows) per pair-row
     constexpr int UPT = PPS * UPR / TW;      // units per thread and step
     static_assert(PPS * UPR % TW == 0, "row-pass units must divide evenly");
-    static_assert(RP <= 16 && (TW % 64) == 0 && NP <= PPS * (LAG + 1), "unsupported geometry");
+    static_assert(RP <= kHalo && (TW % 64) == 0 && NP <= PPS * (LAG + 1), "unsupported geometry");
     static_assert(ROWS == 8 || ROWS == 16, "ballot packing below handles 8 or 16 rows");
 
     __shared__ __attribute__((aligned(16))) uint32_t s_in[2][ROWS][IWD];
@@ -91,7 +96,7 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     // w % 16 == 0, so a vector lies entirely inside the frame or entirely outside.  Outside
     // vectors exist only next to the left/right frame border; they are the mirror image
     // (BORDER_REFLECT_101) of in-frame columns and are assembled in registers from two aligned
-    // loads:   left : t[i] = col(16 - i)      right: t[i] = col(w - 2 - i)
+    // loads:   left : t[i] = col(K - i), K = -gx0 = 16 (or 32)      right: t[i] = col(w - 2 - J - i), J = gx0 - w = 0 (or 16)
     auto ld16 = [&](const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); };
     auto fetch = [&](int s, int v) -> uint4 {
         const int vrow = v / VPR, vcol = v % VPR;
@@ -100,16 +105,16 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
         const uint8_t *rowp = img + (size_t)yy * w;
         if (gx0 >= 0 && gx0 + 16 <= w)
             return ld16(rowp + gx0);
-        if (gx0 == -16) {
-            const uint4 A = ld16(rowp), B = ld16(rowp + 16);
+        if (gx0 < 0 && gx0 >= -kHalo) {
+            const uint4 A = ld16(rowp - gx0 - 16), B = ld16(rowp - gx0);
             const uint32_t r0 = __builtin_bswap32(A.w), r1 = __builtin_bswap32(A.z),
                            r2 = __builtin_bswap32(A.y), r3 = __builtin_bswap32(A.x);
             return make_uint4((r0 << 8) | (B.x & 0xFFu), __builtin_amdgcn_alignbyte(r1, r0, 3),
                               __builtin_amdgcn_alignbyte(r2, r1, 3),
                               __builtin_amdgcn_alignbyte(r3, r2, 3));
         }
-        if (gx0 == w) {
-            const uint4 C = ld16(rowp + w - 32), D = ld16(rowp + w - 16);
+        if (gx0 >= w && gx0 < w + kHalo) {
+            const uint4 C = ld16(rowp + 2 * w - 32 - gx0), D = ld16(rowp + 2 * w - 16 - gx0);
             const uint32_t r0 = __builtin_bswap32(D.w), r1 = __builtin_bswap32(D.z),
                            r2 = __builtin_bswap32(D.y), r3 = __builtin_bswap32(D.x);
             return make_uint4(__builtin_amdgcn_alignbyte(r1, r0, 1),
@@ -161,9 +166,9 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
             const int pr = u / UPR, xq = u % UPR;
             const uint32_t *r0 = &s_in[buf][2 * pr][xq];
             const uint32_t *r1 = &s_in[buf][2 * pr + 1][xq];
-            uint32_t d0[9], d1[9];
+            uint32_t d0[WD], d1[WD];
 #pragma unroll
-            for (int d = 0; d < 9; d++) {
+            for (int d = 0; d < WD; d++) {
                 d0[d] = r0[d];
                 d1[d] = r1[d];
             }
@@ -171,7 +176,7 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
             // accumulator would need a wait state each
             uint32_t a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int d = 0; d < 9; d++) {
+            for (int d = 0; d < WD; d++) {
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     a0[o] = udot4(d0[d], wt.wrow[o][d], a0[o]);
@@ -256,12 +261,13 @@ gauss_fused_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     }
 }
 
-bool build_weights(const TapsQ8 &taps, int RP, FusedWeights *wt)
+template <int HALO>
+bool build_weights(const TapsQ8 &taps, int RP, FusedWeights<HALO> *wt)
 {
     const int r = taps.ksize / 2;
-    if (r > RP || RP > 16)
+    if (r > RP || RP > HALO)
         return false;
-    uint32_t P[2 * 16 + 2] = {};   // zero-padded taps, centred at RP
+    uint32_t P[2 * kMaxHalo + 2] = {};   // zero-padded taps, centred at RP
     for (int i = 0; i < taps.ksize; i++) {
         if (taps.t[i] > 255)
             return false;
@@ -269,8 +275,8 @@ bool build_weights(const TapsQ8 &taps, int RP, FusedWeights *wt)
     }
     memset(wt, 0, sizeof(*wt));
     for (int o = 0; o < 4; o++)
-        for (int j = 0; j < 36; j++) {
-            const int i = j - (kHalo - RP + o);
+        for (int j = 0; j < 4 + 2 * HALO; j++) {
+            const int i = j - (HALO - RP + o);
             if (i >= 0 && i <= 2 * RP)
                 wt->wrow[o][j / 4] |= P[i] << (8 * (j % 4));
         }
@@ -283,7 +289,7 @@ bool build_weights(const TapsQ8 &taps, int RP, FusedWeights *wt)
     return true;
 }
 
-int padded_radius(int r) { return r <= 4 ? 4 : (r <= 8 ? 8 : 16); }
+int padded_radius(int r) { return r <= 4 ? 4 : (r <= 8 ? 8 : (r <= 16 ? 16 : (r <= 24 ? 24 : 32))); }
 
 // strip width that wastes the fewest columns (ties: the wider strip, fewer halo re-reads)
 int pick_tw(int w)
@@ -300,9 +306,9 @@ int pick_tw(int w)
     return best;
 }
 
-template <int TW>
+template <int TW, int HALO>
 int launch_tw(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n, int h, int w,
-              int RP, const FusedWeights &wt, hipStream_t st)
+              int RP, const FusedWeights<HALO> &wt, hipStream_t st)
 {
     const int nstrips = cdiv(w, TW);
     const int w32 = words_per_row(w);
@@ -318,16 +324,39 @@ int launch_tw(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int 
         else                                               \
             VA_GF_LAUNCH(RPV, false, true);                \
     } while (0)
-    if (RP == 4)
-        VA_GF_RP(4);
-    else if (RP == 8)
-        VA_GF_RP(8);
-    else
-        VA_GF_RP(16);
+    if constexpr (HALO == 16) {
+        if (RP == 4)
+            VA_GF_RP(4);
+        else if (RP == 8)
+            VA_GF_RP(8);
+        else
+            VA_GF_RP(16);
+    } else {
+        if (RP == 24)
+            VA_GF_RP(24);
+        else
+            VA_GF_RP(32);
+    }
 #undef VA_GF_RP
 #undef VA_GF_LAUNCH
     VA_LAUNCH_CHECK("gauss_fused_kernel");
     return VA_OK;
+}
+
+template <int HALO>
+int launch_halo(const uint8_t *src, uint8_t *dst, uint32_t *bits, int thresh, int n, int h, int w, int RP,
+                const TapsQ8 &taps, hipStream_t st)
+{
+    FusedWeights<HALO> wt;
+    VA_REQUIRE(build_weights(taps, RP, &wt), "fused gaussian: cannot build the weight tables");
+    switch (pick_tw(w)) {
+    case 128:
+        return launch_tw<128>(src, dst, bits, thresh, n, h, w, RP, wt, st);
+    case 192:
+        return launch_tw<192>(src, dst, bits, thresh, n, h, w, RP, wt, st);
+    default:
+        return launch_tw<256>(src, dst, bits, thresh, n, h, w, RP, wt, st);
+    }
 }
 
 }  // namespace
@@ -336,7 +365,10 @@ bool gauss_fused_supported(int w, int h, const TapsQ8 &taps)
 {
     if (w < 32 || h < 32 || (w % 16) != 0)   // single reflection; 16-byte aligned rows
         return false;
-    if (taps.ksize < 3 || taps.ksize / 2 > 16)
+    const int r = taps.ksize / 2;
+    if (taps.ksize < 3 || r > kMaxHalo)
+        return false;
+    if (r > 16 && (w < 64 || h < 64))        // the wide kernels: two mirrored vectors per row end, 32 mirrored rows
         return false;
     int sum = 0;
     for (int i = 0; i < taps.ksize; i++) {
@@ -356,18 +388,11 @@ int launch_gauss_fused_u8(const uint8_t *src, uint8_t *dst, uint32_t *bits, int 
     if (n == 0)
         return VA_OK;
     const int RP = padded_radius(taps.ksize / 2);
-    FusedWeights wt;
-    VA_REQUIRE(build_weights(taps, RP, &wt), "fused gaussian: cannot build the weight tables");
     VA_REQUIRE(reinterpret_cast<uintptr_t>(src) % 16 == 0,
                "fused gaussian: the frame buffer must be 16-byte aligned");
-    switch (pick_tw(w)) {
-    case 128:
-        return launch_tw<128>(src, dst, bits, thresh, n, h, w, RP, wt, st);
-    case 192:
-        return launch_tw<192>(src, dst, bits, thresh, n, h, w, RP, wt, st);
-    default:
-        return launch_tw<256>(src, dst, bits, thresh, n, h, w, RP, wt, st);
-    }
+    if (RP <= 16)
+        return launch_halo<16>(src, dst, bits, thresh, n, h, w, RP, taps, st);
+    return launch_halo<32>(src, dst, bits, thresh, n, h, w, RP, taps, st);
 }
 
 }  // namespace va
