@@ -26,7 +26,7 @@ def run_case(rng, case=0, allow_big=True):
     if big:
         w = int(rng.choice([640, 1280, 1920, 1936, 2048, 2064, 2560, 3840, 4000]))
     n = int(rng.choice([1, 3, 7, 96, 100, 130])) if not big else int(rng.choice([2, 97]))
-    sigma = float(rng.choice([0.6, 0.8, 1.0, 1.7, 2.0, 3.0, 4.2, 5.0, 5.3, 6.0]))
+    sigma = float(rng.choice([0.6, 0.8, 1.0, 1.7, 2.0, 3.0, 4.2, 5.0, 5.3, 6.0, 7.5, 8.4, 10.0, 10.7, 11.0]))
     thresh = int(rng.integers(5, 60))
     conn = int(rng.choice([4, 8]))
     bg = str(rng.choice(["mean", "none"]))
