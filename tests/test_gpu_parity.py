@@ -655,6 +655,39 @@ def test_small_stencils_peaks_thinning_statistics(ops, oracle):
     assert image.get_image_statistics(img, "box", 3, ret_var=False).shape == img.shape
 
 
+def test_image_statistics_box_tiles(ops, oracle):
+    """box windows up to 31 x 31 run in one LDS-tiled kernel (64 x 64 tiles, sliding sums); larger ones and ellipses
+    go through the row-prefix kernels: same integers, same float64 arithmetic -- against the oracle, and a batch of
+    frames through the C ABI in one call"""
+    from video import _hip
+    from video.analysis import image
+    rng = np.random.default_rng(77)
+    for shape, ksize in (((64, 64), 3), ((65, 130), 7), ((200, 333), 15), ((130, 70), 16), ((31, 500), 10),
+                         ((1, 1), 4), ((3, 200), 15), ((129, 64), 1)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        img[:2] = 255
+        for excl in (False, True):
+            mean, var = image.get_image_statistics(img, "box", ksize, prior=128, exclude_center=excl)
+            rm, rv = oracle.image_statistics(img, "box", ksize, 128, excl)
+            assert np.array_equal(mean, rm) and np.array_equal(var, rv), (shape, ksize, excl)
+    img = rng.integers(0, 256, (90, 150), dtype=np.uint8)
+    m1, v1 = image.get_image_statistics(img, "box", 6, prior=100.5)
+    rm, rv = oracle.image_statistics(img, "box", 6, 100.5, False)
+    assert np.allclose(m1, rm, rtol=1e-12, atol=1e-9) and np.allclose(v1, rv, rtol=1e-9, atol=1e-6)
+    # three frames in one call
+    clip = rng.integers(0, 256, (3, 70, 97), dtype=np.uint8)
+    d, dm, dv = ops._upload(clip), ops._take(clip.size * 8), ops._take(clip.size * 8)
+    try:
+        _hip.check(_hip.lib().va_image_statistics_u8(d.ptr, dm.ptr, dv.ptr, 3, 70, 97, 0, 9, 0.0, 0, None))
+        gm, gv = dm.download(clip.shape, np.float64), dv.download(clip.shape, np.float64)
+    finally:
+        for b in (d, dm, dv):
+            ops._give(b)
+    for f in range(3):
+        rm, rv = oracle.image_statistics(clip[f], "box", 9, 0, False)
+        assert np.array_equal(gm[f], rm) and np.array_equal(gv[f], rv)
+
+
 # ------------------------------------------------------------------------ fused pipeline
 def _engine(**kw):
     from video.engine import FrameEngine

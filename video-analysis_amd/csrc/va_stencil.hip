@@ -293,6 +293,80 @@ image_statistics_prefix_kernel(const uint8_t *__restrict__ src, const uint32_t *
         var_out[e] = (s2 - s1 * s1 / count) / (count - 1.0);
 }
 
+// Box windows up to 31 x 31 (ksize <= 15), uint8: one workgroup per 64 x 64 tile, everything in LDS -- the tile
+// with its zero border, sliding horizontal window sums per row, sliding vertical sums per column -- so a pixel costs
+// 1.3 bytes read and 16 written instead of 4 gathers per window row from the prefix arrays.  The sums are the same
+// integers; the float64 arithmetic after them is the prefix kernel's.
+constexpr int kStT = 64, kStMaxK = 31, kStR = kStT + kStMaxK - 1;
+__global__ void __launch_bounds__(256)
+image_statistics_box_kernel(const uint8_t *__restrict__ src, double *__restrict__ mean_out,
+                            double *__restrict__ var_out, int h, int w, int tiles_x, int tiles_y, int K, int anchor,
+                            double prior, int exclude_center, double count)
+{
+    __shared__ uint8_t s_px[kStR][kStR + 2];
+    __shared__ uint32_t s_h1[kStR][kStT + 1], s_h2[kStR][kStT + 1];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
+    const size_t f = blockIdx.x / ((size_t)tiles_x * tiles_y);
+    const uint8_t *img = src + f * (size_t)h * w;
+    const int X0 = tx * kStT, Y0 = ty * kStT, R = kStT + K - 1;
+    for (int idx = tid; idx < R * R; idx += 256) {
+        const int r = idx / R, c = idx - r * R;
+        const int yy = Y0 - anchor + r, xx = X0 - anchor + c;
+        s_px[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[(size_t)yy * w + xx] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int t = tid; t < R * 4; t += 256) {             // row r, 16 output columns from c0
+        const int r = t >> 2, c0 = (t & 3) * 16;
+        uint32_t a1 = 0, a2 = 0;
+        for (int i = 0; i < K; i++) {
+            const uint32_t v = s_px[r][c0 + i];
+            a1 += v;
+            a2 += v * v;
+        }
+        for (int c = 0; c < 16; c++) {
+            s_h1[r][c0 + c] = a1;
+            s_h2[r][c0 + c] = a2;
+            const uint32_t in = s_px[r][c0 + c + K], out = s_px[r][c0 + c];   // (column R .. R+1: padding, unused)
+            a1 += in - out;
+            a2 += in * in - out * out;
+        }
+    }
+    __syncthreads();
+    const int col = tid & 63, y0 = (tid >> 6) * 16;
+    const int x = X0 + col;
+    uint32_t v1 = 0, v2 = 0;
+    for (int i = 0; i < K; i++) {
+        v1 += s_h1[y0 + i][col];
+        v2 += s_h2[y0 + i][col];
+    }
+    const int nx = min(w, x - anchor + K) - max(0, x - anchor);
+    for (int j = 0; j < 16; j++) {
+        const int y = Y0 + y0 + j;
+        if (x < w && y < h) {
+            long long S1 = v1, S2 = v2;
+            long long N = (long long)nx * (min(h, y - anchor + K) - max(0, y - anchor));
+            if (exclude_center) {
+                const long long c = s_px[y0 + j + anchor][col + anchor];
+                S1 -= c;
+                S2 -= c * c;
+                N -= 1;
+            }
+            const double dS1 = (double)S1, dN = (double)N;
+            const double s1 = dS1 - dN * prior;
+            const double s2 = ((double)S2 - 2.0 * prior * dS1) + dN * prior * prior;
+            const size_t e = (f * h + y) * (size_t)w + x;
+            mean_out[e] = s1 / count + prior;
+            if (var_out)
+                var_out[e] = (s2 - s1 * s1 / count) / (count - 1.0);
+        }
+        if (j < 15) {
+            v1 += s_h1[y0 + j + K][col] - s_h1[y0 + j][col];
+            v2 += s_h2[y0 + j + K][col] - s_h2[y0 + j][col];
+        }
+    }
+}
+
 }  // namespace
 
 int launch_detect_peaks(const uint8_t *src, uint8_t *dst, int n, int h, int w, int include_plateaus,
@@ -378,6 +452,17 @@ int launch_image_statistics(const uint8_t *src, double *mean_out, double *var_ou
         count += se.hi[i] > se.lo[i] ? se.hi[i] - se.lo[i] : 0;
     if (exclude_center)
         count -= 1;
+    bool box = se.ksize <= kStMaxK;                     // every row the same full span
+    for (int i = 0; i < se.ksize; i++)
+        box = box && se.lo[i] == 0 && se.hi[i] == se.ksize;
+    const long long tiles = (long long)n * cdiv(h, kStT) * cdiv(w, kStT);
+    if (box && tiles < (1ll << 31)) {
+        image_statistics_box_kernel<<<(unsigned)tiles, 256, 0, st>>>(src, mean_out, var_out, h, w, cdiv(w, kStT),
+                                                                      cdiv(h, kStT), se.ksize, se.anchor, prior,
+                                                                      exclude_center, count);
+        VA_LAUNCH_CHECK("image_statistics_box_kernel");
+        return VA_OK;
+    }
     if (w <= 65536 && scratch) {
         const size_t rows = (size_t)n * h;
         uint32_t *p1 = (uint32_t *)scratch, *p2 = p1 + rows * ((size_t)w + 1);
