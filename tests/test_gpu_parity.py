@@ -1476,4 +1476,19 @@ def test_pointwise_pre_stages_fold_into_the_engine(oracle):
     want = ((np.clip(col[:3, 8:80, 10:106].astype(np.float64), 20, 220) - 20) * (255 / 200.0)).astype(np.int64).astype(np.uint8)
     assert np.array_equal(keep, want)
     assert L.va_prepare_u8(src.ptr, dst.ptr, 3, 90, 130, 3, 100, 8, 96, 72, -1, 0, 0.0, 0.0, 0.0, 0.0, None) != 0
+    # every mono mode, with and without normalisation, on the four-samples-per-thread path (rows of whole dwords)
+    # and on the one-sample path (width 95)
+    for width, left in ((96, 10), (95, 10), (96, 8), (64, 0), (92, 12)):      # (left % 4 == 0: aligned rows, dword loads)
+        crop = col[:3, 8:80, left:left + width]
+        for mono in (-1, 0, 1, 2, 3):
+            for normalize in (0, 1):
+                out_c = 3 if mono < 0 else 1
+                check(L.va_prepare_u8(src.ptr, dst.ptr, 3, 90, 130, 3, left, 8, width, 72, mono, normalize, 20.0, 220.0,
+                                      255 / 200.0, 0.0, None))
+                got1 = dst.download((3, 72, width, out_c), np.uint8)
+                w0 = crop if mono < 0 else (crop[..., mono:mono + 1] if mono < 3 else
+                                            (crop.astype(np.float64).sum(-1, keepdims=True) / 3.0).astype(np.uint8))
+                if normalize:
+                    w0 = ((np.clip(w0.astype(np.float64), 20, 220) - 20) * (255 / 200.0)).astype(np.int64).astype(np.uint8)
+                assert np.array_equal(got1, w0), (width, left, mono, normalize)
     src.free(); dst.free()

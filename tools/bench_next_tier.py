@@ -83,4 +83,15 @@ res[-1]["iterations"] = it.value
 for rule, nm in ((0, "cv4"), (1, "cv3")):
     timed("va_gaussian_u8_rule sigma=5 %s" % nm,
           lambda: _hip.check(L.va_gaussian_u8_rule(img.data_ptr(), out_u8.data_ptr(), n, h, w, 1, 5.0, rule, S)), n, n * px * 2)
+# A5: crop -> monochrome (float64 mean of three channels) -> normalise, one pass (va_prepare_u8), 64 colour frames
+col = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device=dev, generator=g)
+timed("va_prepare_u8 mono-mean + normalize 1920x1080x3 -> 1920x1080",
+      lambda: _hip.check(L.va_prepare_u8(col.data_ptr(), out_u8.data_ptr(), n, h, w, 3, 0, 0, w, h, 3, 1, 20.0, 220.0,
+                                         255 / 200.0, 0.0, S)), n, n * px * 4)
+timed("va_prepare_u8 crop 1600x900 + channel pick",
+      lambda: _hip.check(L.va_prepare_u8(col.data_ptr(), out_u8.data_ptr(), n, h, w, 3, 160, 90, 1600, 900, 1, 0, 0.0, 0.0,
+                                         0.0, 0.0, S)), n, n * 1600 * 900 * 4)
+timed("va_prepare_u8 crop 1599x900 + channel pick (rows of no whole dwords: one sample per thread)",
+      lambda: _hip.check(L.va_prepare_u8(col.data_ptr(), out_u8.data_ptr(), n, h, w, 3, 160, 90, 1599, 900, 1, 0, 0.0, 0.0,
+                                         0.0, 0.0, S)), n, n * 1599 * 900 * 4)
 print(json.dumps({"next_tier": res}))
