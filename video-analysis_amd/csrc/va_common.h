@@ -153,6 +153,9 @@ int launch_threshold_u8(const uint8_t *src, uint8_t *dst, size_t count, int thre
 int launch_time_difference(const uint8_t *a, const uint8_t *b, int16_t *out, size_t count,
                            hipStream_t st);
 int launch_mono_mean(const uint8_t *src, uint8_t *dst, size_t pixels, hipStream_t st);
+// (va_synth.hip) four samples per thread, table-driven normalisation; false: shape not supported, nothing launched
+bool launch_pointwise_u8_x4(const uint8_t *src, uint8_t *dst, size_t out_samples, int src_c, int mono, int normalize,
+                            double fmin, double fmax, double alpha, double tmin, hipStream_t st);
 // (n, h, w, c) interleaved u8 <-> (n, c, h, wp) planes padded to wp columns by reflection
 int launch_channel_planes(const uint8_t *src, uint8_t *dst, int n, int h, int w, int wp, int c,
                           bool split, hipStream_t st);

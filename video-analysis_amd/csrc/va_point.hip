@@ -656,6 +656,10 @@ int launch_mono_mean(const uint8_t *src, uint8_t *dst, size_t pixels, hipStream_
     VA_REQUIRE(src && dst, "va_mono_mean_u8: NULL argument");
     if (pixels == 0)
         return VA_OK;
+    if (src != dst && launch_pointwise_u8_x4(src, dst, pixels, 3, 3, 0, 0.0, 0.0, 0.0, 0.0, st)) {
+        VA_LAUNCH_CHECK("prepare_u8_x4_kernel");
+        return VA_OK;
+    }
     mono_mean_kernel<<<cdiv((long long)pixels, kBlock), kBlock, 0, st>>>(src, dst, pixels);
     VA_LAUNCH_CHECK("mono_mean_kernel");
     return VA_OK;
@@ -839,6 +843,11 @@ int launch_normalize_u8(const uint8_t *src, uint8_t *dst, size_t count, double f
     VA_REQUIRE(src && dst, "va_normalize_u8: NULL argument");
     if (count == 0)
         return VA_OK;
+    // (in place is fine: a thread reads its four bytes before it writes them)
+    if (launch_pointwise_u8_x4(src, dst, count, 1, -1, 1, fmin, fmax, alpha, tmin, st)) {
+        VA_LAUNCH_CHECK("prepare_u8_x4_kernel");
+        return VA_OK;
+    }
     normalize_u8_kernel<<<cdiv((long long)count, kBlock), kBlock, 0, st>>>(src, dst, count, fmin,
                                                                           fmax, alpha, tmin);
     VA_LAUNCH_CHECK("normalize_u8_kernel");

@@ -248,6 +248,22 @@ int launch_prepare_u8(const uint8_t *src, uint8_t *dst, int n, int src_h, int sr
     return VA_OK;
 }
 
+// a flat run of samples through the four-samples-per-thread kernel (FilterMonochrome / FilterNormalize on their own):
+// false when the shape does not fit it (the caller then runs its one-sample kernel)
+bool launch_pointwise_u8_x4(const uint8_t *src, uint8_t *dst, size_t out_samples, int src_c, int mono, int normalize,
+                            double fmin, double fmax, double alpha, double tmin, hipStream_t st)
+{
+    const int out_c = mono < 0 ? src_c : 1;
+    if (out_samples % 4 != 0 || out_samples >= (1ull << 31) || out_samples % out_c != 0 ||
+        reinterpret_cast<uintptr_t>(dst) % 4 != 0)
+        return false;
+    const int width = (int)(out_samples / out_c);
+    const dim3 grid((unsigned)cdiv((long long)(out_samples / 4), kBlock), 1u, 1u);
+    prepare_u8_x4_kernel<<<grid, kBlock, 0, st>>>(src, dst, 1, width, src_c, 0, 0, width, 1, mono, out_c, normalize, fmin,
+                                                 fmax, alpha, tmin);
+    return true;
+}
+
 int launch_gaussian_noise(void *dst, int dtype, size_t count, double mean, double stdev, uint64_t seed,
                           uint64_t first_index, hipStream_t st)
 {
