@@ -446,8 +446,8 @@ def main():
         return cpu_baseline_f32_main(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3_1080p_full_chain",
                     choices=sorted(WORKLOADS) + sorted(F32_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override frames per step per GPU")
