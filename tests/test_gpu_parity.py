@@ -365,6 +365,16 @@ def test_morphology_golden_and_oracle(ops, golden, oracle):
                     # bit-packed kernel used inside the pipeline == u8 kernel on binary masks
                     assert np.array_equal(ops.morph(b, op, sh, k, implementation="bits"),
                                           oracle.morph_u8(b, o, so, k)), (shape, op, sh, k, "bits")
+    # rows of whole dwords: the four-samples-per-thread kernels (packed 16-bit extremes, v_alignbyte windows),
+    # large elements included; the other widths above ran the one-sample kernels
+    for shape in ((1, 40, 4), (2, 33, 128), (1, 20, 1920), (1, 70, 8), (3, 64, 36)):
+        g = rng.integers(0, 256, shape, dtype=np.uint8)
+        g[0, :2] = 255
+        g[-1, :, -5:] = 0
+        for op, o in (("erode", oracle.ERODE), ("dilate", oracle.DILATE)):
+            for sh, so in (("rect", oracle.RECT), ("cross", oracle.CROSS), ("ellipse", oracle.ELLIPSE)):
+                for k in (3, 6, 15, 31):
+                    assert np.array_equal(ops.morph(g, op, sh, k), oracle.morph_u8(g, o, so, k)), (shape, op, sh, k)
 
 
 # --------------------------------------------------------------------------- labelling

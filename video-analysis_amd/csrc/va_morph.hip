@@ -676,9 +676,126 @@ morph_u8_line_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     dst[e] = (uint8_t)best;
 }
 
+namespace {
+
+// Grey-level erosion / dilation, four samples per thread (rows of whole, aligned dwords).  The running extreme of four
+// neighbouring samples is kept as two pairs of 16-bit lanes (even bytes, odd bytes: v_pk_max_u16 / v_pk_min_u16 on
+// both), and an element of the structuring element contributes the frame dword that starts `s` bytes from the
+// thread's own -- one v_alignbyte of two aligned dwords -- so a thread issues (span + 3) / 4 + 1 loads per row of the
+// element instead of four byte loads per element.  Pixels outside the frame never win (OpenCV's default border).
+// grid = (dwords of a row, rows, frames): no division per sample.  The one-sample kernels above remain for other
+// widths; they are bound by the launch rate of waves.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+template <bool DILATE>
+struct Extreme4 {
+    us2 even, odd;
+    __device__ __forceinline__ Extreme4()
+    {
+        const unsigned short v = DILATE ? 0 : 255;
+        even = us2{v, v};
+        odd = us2{v, v};
+    }
+    __device__ __forceinline__ void take(uint32_t d)
+    {
+        const us2 e = __builtin_bit_cast(us2, d & 0x00FF00FFu), o = __builtin_bit_cast(us2, (d >> 8) & 0x00FF00FFu);
+        even = DILATE ? __builtin_elementwise_max(even, e) : __builtin_elementwise_min(even, e);
+        odd = DILATE ? __builtin_elementwise_max(odd, o) : __builtin_elementwise_min(odd, o);
+    }
+    __device__ __forceinline__ uint32_t word() const
+    {
+        return __builtin_bit_cast(uint32_t, even) | (__builtin_bit_cast(uint32_t, odd) << 8);
+    }
+};
+
+// every row i of the element: samples x + lo[i] - anchor ... x + hi[i] - 1 - anchor of row y + i - anchor
+template <bool DILATE>
+__global__ void __launch_bounds__(kBlock)
+morph_u8_rows_x4_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w, RowSpans se)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x, wq = w >> 2;
+    if (q >= wq)
+        return;
+    const int y = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const uint32_t *frame = reinterpret_cast<const uint32_t *>(src + f * (size_t)h * w);
+    const uint32_t neutral = DILATE ? 0u : 0xFFFFFFFFu;
+    Extreme4<DILATE> best;
+    for (int i = 0; i < se.ksize; i++) {
+        const int yy = y + i - se.anchor;
+        const int lo = se.lo[i], hi = se.hi[i];
+        if (yy < 0 || yy >= h || hi <= lo)
+            continue;                                    // (uniform)
+        const uint32_t *row = frame + (size_t)yy * wq;
+        // byte offsets lo - anchor ... hi - 1 - anchor from the thread's dword; aligned dword d holds bytes 4d ... 4d+3
+        int off = lo - se.anchor;                        // uniform
+        int d = q + (off >> 2);                          // floor division
+        uint32_t cur = (d >= 0 && d < wq) ? row[d] : neutral;
+        uint32_t nxt = (d + 1 >= 0 && d + 1 < wq) ? row[d + 1] : neutral;
+        for (int s = lo; s < hi; s++, off++) {
+            const int sh = off & 3;
+            if (sh == 0 && s != lo) {
+                d++;
+                cur = nxt;
+                nxt = (d + 1 >= 0 && d + 1 < wq) ? row[d + 1] : neutral;
+            }
+            best.take(__builtin_amdgcn_alignbyte(nxt, cur, sh));
+        }
+    }
+    reinterpret_cast<uint32_t *>(dst + (f * h + y) * (size_t)w)[q] = best.word();
+}
+
+// a column of `ksize` rows (the second pass of a rectangle)
+template <bool DILATE>
+__global__ void __launch_bounds__(kBlock)
+morph_u8_vert_x4_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w, int ksize, int anchor)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x, wq = w >> 2;
+    if (q >= wq)
+        return;
+    const int y = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const uint32_t *frame = reinterpret_cast<const uint32_t *>(src + f * (size_t)h * w);
+    int a = y - anchor, b = y - anchor + ksize - 1;
+    a = a < 0 ? 0 : a;
+    b = b >= h ? h - 1 : b;
+    Extreme4<DILATE> best;
+    for (int t = a; t <= b; t++)
+        best.take(frame[(size_t)t * wq + q]);
+    reinterpret_cast<uint32_t *>(dst + (f * h + y) * (size_t)w)[q] = best.word();
+}
+
+}  // namespace
+
 int launch_morph_u8(const uint8_t *src, uint8_t *dst, int n, int h, int w, int op,
                     const RowSpans &se, hipStream_t st, uint8_t *scratch)
 {
+    if (w % 4 == 0 && h <= 65535 && n <= 65535 && n > 0 && src != dst && reinterpret_cast<uintptr_t>(src) % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(dst) % 4 == 0 && (!scratch || reinterpret_cast<uintptr_t>(scratch) % 4 == 0)) {
+        const dim3 grid((unsigned)cdiv(w / 4, kBlock), (unsigned)h, (unsigned)n);
+        bool full = scratch != nullptr && se.ksize >= 3;     // a rectangle: one row of the element, then a column
+        for (int i = 0; i < se.ksize && full; i++)
+            full = se.lo[i] == 0 && se.hi[i] == se.ksize;
+        if (full) {
+            RowSpans line = {};
+            line.ksize = 1;
+            line.anchor = 0;
+            line.lo[0] = (int8_t)(-se.anchor);
+            line.hi[0] = (int8_t)(se.ksize - se.anchor);
+            if (op == VA_MORPH_DILATE) {
+                morph_u8_rows_x4_kernel<true><<<grid, kBlock, 0, st>>>(src, scratch, h, w, line);
+                morph_u8_vert_x4_kernel<true><<<grid, kBlock, 0, st>>>(scratch, dst, h, w, se.ksize, se.anchor);
+            } else {
+                morph_u8_rows_x4_kernel<false><<<grid, kBlock, 0, st>>>(src, scratch, h, w, line);
+                morph_u8_vert_x4_kernel<false><<<grid, kBlock, 0, st>>>(scratch, dst, h, w, se.ksize, se.anchor);
+            }
+        } else if (op == VA_MORPH_DILATE) {
+            morph_u8_rows_x4_kernel<true><<<grid, kBlock, 0, st>>>(src, dst, h, w, se);
+        } else {
+            morph_u8_rows_x4_kernel<false><<<grid, kBlock, 0, st>>>(src, dst, h, w, se);
+        }
+        VA_LAUNCH_CHECK("morph_u8_x4 kernels");
+        return VA_OK;
+    }
     bool rect = scratch != nullptr && se.ksize >= 3;
     for (int i = 0; i < se.ksize && rect; i++)
         rect = se.lo[i] == 0 && se.hi[i] == se.ksize;
