@@ -644,7 +644,10 @@ def test_small_stencils_peaks_thinning_statistics(ops, oracle):
     yy, xx = np.mgrid[:90, :130]
     blob = (((xx - 40) / 30.0) ** 2 + ((yy - 45) / 18.0) ** 2 <= 1) | (abs(xx - 95) + abs(yy - 40) < 25)
     for m in (blob.astype(np.uint8) * 255, blob.astype(np.uint8), np.zeros((10, 12), np.uint8),
-              np.ones((9, 9), np.uint8), (rng.random((60, 70)) < 0.7).astype(np.uint8) * 255):
+              np.ones((9, 9), np.uint8), (rng.random((60, 70)) < 0.7).astype(np.uint8) * 255,
+              # rows of whole dwords: erosion and the rest of a step as four-sample kernels
+              blob[:88, :128].astype(np.uint8) * 255, (rng.random((64, 72)) < 0.8).astype(np.uint8) * 200,
+              rng.integers(0, 256, (40, 64), dtype=np.uint8), np.full((12, 8), 255, np.uint8)):
         skel, it = ops.mask_thinning(m)
         rs, rit = oracle.mask_thinning(m)
         assert it == rit and np.array_equal(skel, rs)

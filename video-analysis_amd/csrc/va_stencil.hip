@@ -154,6 +154,44 @@ thinning_step_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ erod
         atomicAdd(nonzero, (unsigned long long)__popcll(b));
 }
 
+// The second half of a thinning step for rows of whole dwords, four samples per thread: `eroded` is already there
+// (va_morph_u8's four-sample kernel); temp = dilate(eroded) from five dwords of it, sat(img - temp), skel |=, count.
+// Bytewise extremes and the saturating difference run on pairs of 16-bit lanes (even bytes, odd bytes).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(kBlock)
+thinning_tail_x4_kernel(const uint8_t *__restrict__ img, const uint8_t *__restrict__ eroded, uint8_t *__restrict__ skel,
+                        int h, int w, unsigned long long *__restrict__ nonzero)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x, wq = w >> 2;
+    const int y = blockIdx.y;
+    const size_t f = blockIdx.z;
+    unsigned cnt = 0;
+    if (q < wq) {
+        const uint32_t *E = reinterpret_cast<const uint32_t *>(eroded + f * (size_t)h * w);
+        const size_t at = (size_t)y * wq + q;
+        const uint32_t c = E[at];
+        const uint32_t l = q > 0 ? E[at - 1] : 0u, r = q + 1 < wq ? E[at + 1] : 0u;          // the border never wins
+        const uint32_t u = y > 0 ? E[at - wq] : 0u, d = y + 1 < h ? E[at + wq] : 0u;
+        const uint32_t left = __builtin_amdgcn_alignbyte(c, l, 3), right = __builtin_amdgcn_alignbyte(r, c, 1);
+        auto even = [](uint32_t v) { return __builtin_bit_cast(us2, v & 0x00FF00FFu); };
+        auto odd = [](uint32_t v) { return __builtin_bit_cast(us2, (v >> 8) & 0x00FF00FFu); };
+        us2 te = even(c), to = odd(c);
+        for (uint32_t v : {left, right, u, d}) {
+            te = __builtin_elementwise_max(te, even(v));
+            to = __builtin_elementwise_max(to, odd(v));
+        }
+        const uint32_t px = reinterpret_cast<const uint32_t *>(img + f * (size_t)h * w)[at];
+        const us2 de = __builtin_elementwise_sub_sat(even(px), te), dd = __builtin_elementwise_sub_sat(odd(px), to);
+        const uint32_t diff = __builtin_bit_cast(uint32_t, de) | (__builtin_bit_cast(uint32_t, dd) << 8);
+        uint32_t *sk = reinterpret_cast<uint32_t *>(skel + f * (size_t)h * w);
+        sk[at] |= diff;
+        cnt = __popc((((c & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | c) & 0x80808080u);                  // non-zero bytes of c
+    }
+    const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+    if ((threadIdx.x & 63) == 0 && (b0 | b1 | b2))
+        atomicAdd(nonzero, (unsigned long long)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)));
+}
+
 // get_image_statistics: window sums of (img - prior) and its square over a row-span element
 // with zero border (cv2.boxFilter(normalize=False) / cv2.filter2D(ellipse), BORDER_CONSTANT):
 //   mean = s1/count + prior ; var = (s2 - s1^2/count)/(count - 1)
@@ -427,6 +465,22 @@ int launch_thinning_step(const uint8_t *img, uint8_t *eroded, uint8_t *skel, int
     if (total == 0)
         return VA_OK;
     // `nonzero` is this iteration's own counter; the caller zeroes the counter array once
+    // `nonzero` is this iteration's own counter; the caller zeroes the counter array once
+    if (w % 4 == 0 && h <= 65535 && n <= 65535 && reinterpret_cast<uintptr_t>(img) % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(eroded) % 4 == 0 && reinterpret_cast<uintptr_t>(skel) % 4 == 0) {
+        // two launches of four-sample kernels: the erosion (va_morph.hip), then the rest of the step
+        RowSpans cross;
+        int rc = make_row_spans(VA_SHAPE_CROSS, 3, &cross);
+        if (rc)
+            return rc;
+        rc = launch_morph_u8(img, eroded, n, h, w, VA_MORPH_ERODE, cross, st, nullptr);
+        if (rc)
+            return rc;
+        const dim3 grid((unsigned)cdiv(w / 4, kBlock), (unsigned)h, (unsigned)n);
+        thinning_tail_x4_kernel<<<grid, kBlock, 0, st>>>(img, eroded, skel, h, w, nonzero);
+        VA_LAUNCH_CHECK("thinning_tail_x4_kernel");
+        return VA_OK;
+    }
     thinning_step_kernel<<<cdiv((long long)total, kBlock), kBlock, 0, st>>>(img, eroded, skel, h, w,
                                                                            total, nonzero);
     VA_LAUNCH_CHECK("thinning_step_kernel");
