@@ -1456,6 +1456,31 @@ stats_from_labels_kernel(const int32_t *__restrict__ labels, int h, int w, int w
     int64_t *fstats = stats + (size_t)f * max_labels * VA_STATS_STRIDE;
     const int x0 = wi << 5, x1 = min(w, x0 + 32);
     int cur = 0, xs = 0;
+    if (x1 - x0 == 32 && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(labels) & 15) == 0) {
+        // the thread's 128 bytes as eight 16-byte loads, all in flight at once (32 dependent 4-byte loads at a
+        // 128-byte stride between lanes made this kernel 1.9 ms per 64 x 1080p)
+        int4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            v[k] = reinterpret_cast<const int4 *>(row + x0)[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int ls[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int l = ls[j], x = x0 + 4 * k + j;
+                if (l != cur) {
+                    if (cur >= 1 && cur <= max_labels)
+                        stats_add(fstats + (size_t)(cur - 1) * VA_STATS_STRIDE, y, xs, x - xs);
+                    cur = l;
+                    xs = x;
+                }
+            }
+        }
+        if (cur >= 1 && cur <= max_labels)
+            stats_add(fstats + (size_t)(cur - 1) * VA_STATS_STRIDE, y, xs, x1 - xs);
+        return;
+    }
     for (int x = x0; x <= x1; x++) {
         int l = x < x1 ? row[x] : 0;
         if (l != cur) {
