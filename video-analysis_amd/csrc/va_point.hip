@@ -685,6 +685,38 @@ channel_planes_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst
     const uint8_t *inter_c = (SPLIT ? src : nullptr);
     uint8_t *inter = SPLIT ? nullptr : dst;
     const size_t inter_row = rowi * (size_t)w * C;
+    // four whole pixels inside the frame whose 4 C interleaved bytes are C aligned dwords: dword loads and stores on
+    // both sides (the byte gathers / scatters below made a colour blur four times the cost of its three planes)
+    const uint8_t *inter_any = SPLIT ? src : dst;
+    if (C > 1 && xq + 3 < w && ((w * C) & 3) == 0 && (reinterpret_cast<uintptr_t>(inter_any) & 3) == 0) {
+        uint32_t in[C], out[C];
+        uint8_t b[4 * C], o[4 * C];
+        if (SPLIT) {
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                in[c] = reinterpret_cast<const uint32_t *>(src + inter_row + (size_t)xq * C)[c];
+            memcpy(b, in, 4 * C);
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                *reinterpret_cast<uint32_t *>(dst + ((f * C + c) * h + y) * (size_t)wp + xq) =
+                    (uint32_t)b[c] | ((uint32_t)b[C + c] << 8) | ((uint32_t)b[2 * C + c] << 16) | ((uint32_t)b[3 * C + c] << 24);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                in[c] = *reinterpret_cast<const uint32_t *>(src + ((f * C + c) * h + y) * (size_t)wp + xq);
+            memcpy(b, in, 4 * C);                      // b[4 c + i]: channel c of pixel i
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    o[i * C + c] = b[4 * c + i];
+            memcpy(out, o, 4 * C);
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                reinterpret_cast<uint32_t *>(dst + inter_row + (size_t)xq * C)[c] = out[c];
+        }
+        return;
+    }
     if (SPLIT) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
