@@ -750,7 +750,7 @@ int va_mask_thinning_u8(uint8_t *img, uint8_t *scratch, uint8_t *skel, int h, in
     // a 3x3-cross erosion empties any mask within min(h,w)/2 + 1 steps, except one that fills the
     // frame (the border never wins): the reference would loop forever there, we stop
     const int max_it = (h < w ? h : w) / 2 + 2;
-    // One counter of surviving pixels per iteration; the exit condition is read back once per
+    // One flag per iteration (set when a pixel survived the erosion); the exit condition is read back once per
     // kCheck iterations (steps enqueued past the emptying one see an empty image and change
     // nothing: eroded = temp = 0, skeleton |= 0), so the host waits ceil(iterations / kCheck)
     // times instead of once per step.

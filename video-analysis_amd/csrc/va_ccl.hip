@@ -1561,15 +1561,32 @@ struct BitImage {
 __device__ __forceinline__ int code_dx(int s) { return (0x1 | 0x2 | 0x80) >> s & 1 ? 1 : ((0x8 | 0x10 | 0x20) >> s & 1 ? -1 : 0); }
 __device__ __forceinline__ int code_dy(int s) { return (0x2 | 0x4 | 0x8) >> s & 1 ? -1 : ((0x20 | 0x40 | 0x80) >> s & 1 ? 1 : 0); }
 
+// the eight neighbours of (x, y) as a mask, bit s = the pixel in direction s: eight independent loads (clamped
+// coordinates, the result masked), one memory round trip per step of the walk instead of one per probed neighbour
+__device__ __forceinline__ uint32_t neighbours8(const BitImage &im, int x, int y)
+{
+    uint32_t nb = 0;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int xx = x + code_dx(s), yy = y + code_dy(s);
+        const bool in = (unsigned)xx < (unsigned)im.w && (unsigned)yy < (unsigned)im.h;
+        const int xc = min(max(xx, 0), im.w - 1), yc = min(max(yy, 0), im.h - 1);
+        const uint32_t bit = (im.bits[(size_t)yc * im.w32 + (xc >> 5)] >> (xc & 31)) & 1u;
+        nb |= (in ? bit : 0u) << s;
+    }
+    return nb;
+}
+
 template <class Emit>
 __device__ void trace_outer_border(const BitImage &im, int x0, int y0, Emit &emit)
 {
     int s_end = 4, s = 4, x1, y1;
+    const uint32_t nb0 = neighbours8(im, x0, y0);
     do {
         s = (s - 1) & 7;
         x1 = x0 + code_dx(s);
         y1 = y0 + code_dy(s);
-    } while (!im.at(x1, y1) && s != s_end);
+    } while (!((nb0 >> s) & 1u) && s != s_end);
     if (s == s_end) {   // single pixel
         emit(x0, y0);
         return;
@@ -1578,11 +1595,12 @@ __device__ void trace_outer_border(const BitImage &im, int x0, int y0, Emit &emi
     const long long max_steps = 8ll * im.h * im.w + 16;   // a border visits a pixel at most 8 times
     for (long long step = 0; step < max_steps; step++) {
         int x4 = x3, y4 = y3;
+        const uint32_t nb = neighbours8(im, x3, y3);
         while (s < 15) {
             ++s;
             x4 = x3 + code_dx(s & 7);
             y4 = y3 + code_dy(s & 7);
-            if (im.at(x4, y4))
+            if ((nb >> (s & 7)) & 1u)
                 break;
         }
         s &= 7;

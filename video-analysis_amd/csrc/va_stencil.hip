@@ -149,9 +149,8 @@ thinning_step_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ erod
         eroded_out[e] = (uint8_t)ec;
         nz = ec != 0;
     }
-    const unsigned long long b = __ballot(nz);
-    if ((threadIdx.x & 63) == 0 && b)
-        atomicAdd(nonzero, (unsigned long long)__popcll(b));
+    if (__ballot(nz) && (threadIdx.x & 63) == 0)      // (a flag, not a count: see thinning_tail_x4_kernel)
+        *nonzero = 1ull;
 }
 
 // The second half of a thinning step for rows of whole dwords, four samples per thread: `eroded` is already there
@@ -187,9 +186,10 @@ thinning_tail_x4_kernel(const uint8_t *__restrict__ img, const uint8_t *__restri
         sk[at] |= diff;
         cnt = __popc((((c & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | c) & 0x80808080u);                  // non-zero bytes of c
     }
-    const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
-    if ((threadIdx.x & 63) == 0 && (b0 | b1 | b2))
-        atomicAdd(nonzero, (unsigned long long)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)));
+    // the host only asks whether anything survived: a plain store of 1 (8 k waves adding to one counter took most
+    // of this kernel's 18 us)
+    if (__ballot(cnt != 0) && (threadIdx.x & 63) == 0)
+        *nonzero = 1ull;
 }
 
 // get_image_statistics: window sums of (img - prior) and its square over a row-span element
