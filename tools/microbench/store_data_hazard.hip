@@ -1,16 +1,22 @@
-// A 16-byte buffer store followed at once by vector writes to its data registers: is the stored float4 intact?
-// LLVM inserts the wait state itself when soffset is a constant and none when soffset is a register
-// (GCNHazardRecognizer::createsVALUHazard); here both forms are issued by hand, with and without wait states, while
-// the whole chip streams 1 GiB of such stores (the stores have to wait for the memory pipeline).
+// A 16-byte store followed by vector writes to its data registers: how many wait states keep the stored float4 intact?
+// LLVM puts `s_nop 1` (two wait states) behind buffer stores whose soffset is a constant and behind global stores, and
+// nothing behind buffer stores whose soffset is a register (GCNHazardRecognizer::createsVALUHazard).  Here every form
+// is issued by hand with 0 ... 4 wait states, while the whole chip streams 1 GiB of such stores, so that the stores
+// have to wait for the memory pipeline.  MI355X (profiles/r03_store_hazard.txt): constant soffset / global: 23 % of
+// the first dwords wrong with 0 wait states, 0.8 % with 1, none from 2 on (the compiler's choice is right); register
+// soffset: 0.45 % wrong with 0 wait states (the compiler's choice), none from 1 on; 8-byte stores: never.
 //   hipcc --offload-arch=gfx950 -O2 store_data_hazard.hip -o store_data_hazard && ./store_data_hazard
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 
-typedef int v4i __attribute__((ext_vector_type(4)));
+#define FILL "v_mov_b32 v20, %0\n\tv_add_u32 v21, 1, %0\n\tv_add_u32 v22, 2, %0\n\tv_add_u32 v23, 3, %0\n\ts_nop 4\n\t"
+#define SMASH "v_mov_b32 v20, %4\n\tv_mov_b32 v21, %4\n\tv_mov_b32 v22, %4\n\tv_mov_b32 v23, %4"
+#define CLOB "v20", "v21", "v22", "v23", "memory"
 
-template <int MODE>   // 0: register soffset, no gap; 1: register soffset, s_nop 3; 2: constant soffset 0, no gap;
-                      // 3: an 8-byte store (dwordx2), register soffset, no gap
+// KIND 0: buffer_store_dwordx4, register soffset; 1: buffer_store_dwordx4, constant soffset (offset in the vector
+// register); 2: global_store_dwordx4; 3: buffer_store_dwordx2, register soffset.  WS = wait states (0: none)
+template <int KIND, int WS>
 __global__ void __launch_bounds__(256) writer(uint32_t *out, int iters, uint32_t stride_bytes)
 {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -18,41 +24,39 @@ __global__ void __launch_bounds__(256) writer(uint32_t *out, int iters, uint32_t
     const uint32_t voff = t * 16u;
     for (int it = 0; it < iters; it++) {
         const uint32_t a = 0x10000000u + (uint32_t)it * 0x10000u + (t & 0xFFFFu), junk = 0xDEAD0000u + it;
-        uint32_t soff = (uint32_t)it * stride_bytes;
-        soff = __builtin_amdgcn_readfirstlane(soff);
-        if (MODE == 0)
-            asm volatile("v_mov_b32 v20, %0\n\tv_add_u32 v21, 1, %0\n\tv_add_u32 v22, 2, %0\n\tv_add_u32 v23, 3, %0\n\ts_nop 4\n\t"
-                         "buffer_store_dwordx4 v[20:23], %1, %2, %3 offen\n\t"
-                         "v_mov_b32 v20, %4\n\tv_mov_b32 v21, %4\n\tv_mov_b32 v22, %4\n\tv_mov_b32 v23, %4"
-                         :: "v"(a), "v"(voff), "s"(rsrc), "s"(soff), "v"(junk) : "v20", "v21", "v22", "v23", "memory");
-        else if (MODE == 1)
-            asm volatile("v_mov_b32 v20, %0\n\tv_add_u32 v21, 1, %0\n\tv_add_u32 v22, 2, %0\n\tv_add_u32 v23, 3, %0\n\ts_nop 4\n\t"
-                         "buffer_store_dwordx4 v[20:23], %1, %2, %3 offen\n\ts_nop 3\n\t"
-                         "v_mov_b32 v20, %4\n\tv_mov_b32 v21, %4\n\tv_mov_b32 v22, %4\n\tv_mov_b32 v23, %4"
-                         :: "v"(a), "v"(voff), "s"(rsrc), "s"(soff), "v"(junk) : "v20", "v21", "v22", "v23", "memory");
-        else if (MODE == 3)
-            asm volatile("v_mov_b32 v20, %0\n\tv_add_u32 v21, 1, %0\n\tv_add_u32 v22, 2, %0\n\tv_add_u32 v23, 3, %0\n\ts_nop 4\n\t"
-                         "buffer_store_dwordx2 v[20:21], %1, %2, %3 offen\n\t"
-                         "v_mov_b32 v20, %4\n\tv_mov_b32 v21, %4\n\tv_mov_b32 v22, %4\n\tv_mov_b32 v23, %4"
-                         :: "v"(a), "v"(voff), "s"(rsrc), "s"(soff), "v"(junk) : "v20", "v21", "v22", "v23", "memory");
-        else {
-            const uint32_t vo = voff + soff;
-            asm volatile("v_mov_b32 v20, %0\n\tv_add_u32 v21, 1, %0\n\tv_add_u32 v22, 2, %0\n\tv_add_u32 v23, 3, %0\n\ts_nop 4\n\t"
-                         "buffer_store_dwordx4 v[20:23], %1, %2, 0 offen\n\t"
-                         "v_mov_b32 v20, %3\n\tv_mov_b32 v21, %3\n\tv_mov_b32 v22, %3\n\tv_mov_b32 v23, %3"
-                         :: "v"(a), "v"(vo), "s"(rsrc), "v"(junk) : "v20", "v21", "v22", "v23", "memory");
+        const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)it * stride_bytes);
+        const uint32_t vo = voff + soff;
+        const uint64_t gaddr = (uint64_t)out + vo;
+#define GAP(n) ((n) == 0 ? "" : (n) == 1 ? "s_nop 0\n\t" : (n) == 2 ? "s_nop 1\n\t" : (n) == 3 ? "s_nop 2\n\t" : "s_nop 3\n\t")
+        if (KIND == 0) {
+            if (WS == 0) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, %3 offen\n\t" SMASH :: "v"(a), "v"(voff), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 1) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, %3 offen\n\ts_nop 0\n\t" SMASH :: "v"(a), "v"(voff), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 2) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, %3 offen\n\ts_nop 1\n\t" SMASH :: "v"(a), "v"(voff), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 4) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, %3 offen\n\ts_nop 3\n\t" SMASH :: "v"(a), "v"(voff), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+        } else if (KIND == 1) {
+            if (WS == 0) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, 0 offen\n\t" SMASH :: "v"(a), "v"(vo), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 1) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, 0 offen\n\ts_nop 0\n\t" SMASH :: "v"(a), "v"(vo), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 2) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, 0 offen\n\ts_nop 1\n\t" SMASH :: "v"(a), "v"(vo), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 3) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, 0 offen\n\ts_nop 2\n\t" SMASH :: "v"(a), "v"(vo), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 4) asm volatile(FILL "buffer_store_dwordx4 v[20:23], %1, %2, 0 offen\n\ts_nop 3\n\t" SMASH :: "v"(a), "v"(vo), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+        } else if (KIND == 2) {
+            if (WS == 0) asm volatile(FILL "global_store_dwordx4 %1, v[20:23], off\n\t" SMASH :: "v"(a), "v"(gaddr), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 1) asm volatile(FILL "global_store_dwordx4 %1, v[20:23], off\n\ts_nop 0\n\t" SMASH :: "v"(a), "v"(gaddr), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 2) asm volatile(FILL "global_store_dwordx4 %1, v[20:23], off\n\ts_nop 1\n\t" SMASH :: "v"(a), "v"(gaddr), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+            if (WS == 3) asm volatile(FILL "global_store_dwordx4 %1, v[20:23], off\n\ts_nop 2\n\t" SMASH :: "v"(a), "v"(gaddr), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
+        } else {
+            if (WS == 0) asm volatile(FILL "buffer_store_dwordx2 v[20:21], %1, %2, %3 offen\n\t" SMASH :: "v"(a), "v"(voff), "s"(rsrc), "s"(soff), "v"(junk) : CLOB);
         }
     }
 }
 
 __global__ void checker(const uint32_t *out, int iters, uint32_t stride_words, uint32_t threads, unsigned long long *bad,
-                        int two)
+                        int nd)
 {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= threads)
         return;
     unsigned b[4] = {0, 0, 0, 0};
-    const int nd = two ? 2 : 4;
     for (int it = 0; it < iters; it++) {
         const uint32_t a = 0x10000000u + (uint32_t)it * 0x10000u + (t & 0xFFFFu);
         const uint32_t *p = out + (size_t)it * stride_words + t * 4;
@@ -64,33 +68,40 @@ __global__ void checker(const uint32_t *out, int iters, uint32_t stride_words, u
             atomicAdd(bad + k, (unsigned long long)b[k]);
 }
 
+static uint32_t *d;
+static unsigned long long *bad;
+static const uint32_t threads = 256u * 1024u, iters = 256;
+
+template <int KIND, int WS>
+static void run(const char *name)
+{
+    unsigned long long h[4];
+    (void)hipMemset(d, 0, (size_t)threads * 16 * iters);
+    (void)hipMemset(bad, 0, 32);
+    writer<KIND, WS><<<threads / 256, 256>>>(d, iters, threads * 16);
+    checker<<<threads / 256, 256>>>(d, iters, threads * 4, threads, bad, KIND == 3 ? 2 : 4);
+    (void)hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost);
+    printf("%-58s %d wait states: wrong dwords x/y/z/w %llu %llu %llu %llu of %u each\n", name, WS, h[0], h[1], h[2], h[3],
+           threads * iters);
+}
+
 int main()
 {
-    const uint32_t threads = 256u * 1024u, iters = 256;
-    const size_t bytes = (size_t)threads * 16 * iters;         // 1 GiB
-    uint32_t *d;
-    unsigned long long *bad, h[4];
-    if (hipMalloc(&d, bytes) != hipSuccess || hipMalloc(&bad, 32) != hipSuccess)
+    if (hipMalloc(&d, (size_t)threads * 16 * iters) != hipSuccess || hipMalloc(&bad, 32) != hipSuccess)
         return 1;
-    const char *names[4] = {"register soffset, vector writes right behind the store", "register soffset, s_nop 3 in between",
-                            "constant soffset (offset in the vector register), writes right behind",
-                            "8-byte store, register soffset, writes right behind"};
-    for (int mode = 0; mode < 4; mode++)
-        for (int rep = 0; rep < 2; rep++) {
-            (void)hipMemset(d, 0, bytes);
-            (void)hipMemset(bad, 0, 32);
-            if (mode == 0)
-                writer<0><<<threads / 256, 256>>>(d, iters, threads * 16);
-            else if (mode == 1)
-                writer<1><<<threads / 256, 256>>>(d, iters, threads * 16);
-            else if (mode == 2)
-                writer<2><<<threads / 256, 256>>>(d, iters, threads * 16);
-            else
-                writer<3><<<threads / 256, 256>>>(d, iters, threads * 16);
-            checker<<<threads / 256, 256>>>(d, iters, threads * 4, threads, bad, mode == 3);
-            (void)hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost);
-            printf("%-72s wrong dwords x/y/z/w: %llu %llu %llu %llu of %u each\n", names[mode], h[0], h[1], h[2], h[3],
-                   threads * iters);
-        }
+    run<0, 0>("buffer_store_dwordx4, register soffset (compiler: 0)");
+    run<0, 1>("buffer_store_dwordx4, register soffset");
+    run<0, 2>("buffer_store_dwordx4, register soffset");
+    run<0, 4>("buffer_store_dwordx4, register soffset");
+    run<1, 0>("buffer_store_dwordx4, constant soffset");
+    run<1, 1>("buffer_store_dwordx4, constant soffset");
+    run<1, 2>("buffer_store_dwordx4, constant soffset (compiler: 2)");
+    run<1, 3>("buffer_store_dwordx4, constant soffset");
+    run<1, 4>("buffer_store_dwordx4, constant soffset");
+    run<2, 0>("global_store_dwordx4");
+    run<2, 1>("global_store_dwordx4");
+    run<2, 2>("global_store_dwordx4 (compiler: 2)");
+    run<2, 3>("global_store_dwordx4");
+    run<3, 0>("buffer_store_dwordx2, register soffset");
     return 0;
 }
