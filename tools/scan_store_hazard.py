@@ -32,5 +32,5 @@ for fn in sys.argv[1:]:
                     if regs(dst)&data:
                         hits+=1
                         if len(ex)<3: ex.append((kern[:70],t[:50],u[:40]))
-    print(fn,"wide buffer stores with register soffset:',total,'| VALU write of their data within 2 instructions:',hits)
+    print(fn,'wide buffer stores with register soffset:',total,'| VALU write of their data within 2 instructions:',hits)
     for e in ex: print('   ',e)
