@@ -89,6 +89,10 @@ int va_malloc(void **dev_ptr, size_t bytes);
 int va_free(void *dev_ptr);
 int va_host_alloc(void **host_ptr, size_t bytes); /* pinned host memory */
 int va_host_free(void *host_ptr);
+/* Host <-> device copies.  Pinned host memory (va_host_alloc, or registered by the caller): asynchronous on `stream`.
+ * Pageable host memory (a NumPy array): the call waits for the stream's earlier work and returns when the copy is
+ * complete -- large asynchronous copies to pageable memory were seen to leave part of the destination unwritten
+ * after the stream had been synchronised. */
 int va_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int va_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int va_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);

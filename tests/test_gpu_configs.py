@@ -403,3 +403,42 @@ def test_stress_slice_round2_paths(oracle):
         for _ in range(40):
             ok, desc = fn(rng)
             assert ok, desc
+
+
+def test_repeated_runs_are_bit_identical():
+    """the same batch through the same chain, several times: every run gives the same bits (a store-data hazard of
+    16-byte buffer stores showed up as run-to-run differences in an experimental kernel: DESIGN.md 13.10,
+    tools/debug/determinism_f32.py / determinism_u8.py run this at full batch size)"""
+    rng = np.random.default_rng(99)
+    n, h, w = 24, 1080, 1920
+    clip = _moving_blob_clip(n, h, w, seed=9, nblobs=30, salt=0.002, noise_tiles=4)
+    eng = _engine(size=(w, h), max_batch=n, background="mean", sigma=5.0, thresh=20,
+                  morphology=(("dilate", "rect", 5), ("erode", "rect", 5)), connectivity=4)
+    first = None
+    for _ in range(4):
+        eng.set_background(np.full((h, w), 100.0), 50)
+        out = eng.run(clip, want=("filtered", "labels", "counts"))
+        if first is None:
+            first = out
+        else:
+            for k in first:
+                assert np.array_equal(out[k], first[k]), k
+    eng.close()
+    f = (rng.random((12, h, w, 3), dtype=np.float32) * 2 - 0.5).astype(np.float32)
+    eng = _engine(size=(w, h), channels=3, dtype=np.float32, max_batch=12, background="ema", bg_rate=0.02, sigma=9.0)
+    first = None
+    for _ in range(4):
+        eng.set_background(np.zeros((h, w, 3), np.float32), 5)
+        out = eng.run(f, want=("filtered",))["filtered"]
+        state, _ = eng.get_background()
+        if first is None:
+            first = (out, state)
+        else:
+            assert np.array_equal(out.view(np.uint32), first[0].view(np.uint32))
+            assert np.array_equal(state.view(np.uint32), first[1].view(np.uint32))
+    eng.close()
+    from video import ops
+    g = (rng.random((8, h, w), dtype=np.float32) * 3 - 1).astype(np.float32)
+    ref = ops.gaussian_blur(g, 5.0)
+    for _ in range(3):
+        assert np.array_equal(ops.gaussian_blur(g, 5.0).view(np.uint32), ref.view(np.uint32))

@@ -228,18 +228,44 @@ int va_host_free(void *host_ptr)
         VA_HIP(hipHostFree(host_ptr));
     return VA_OK;
 }
+// Host memory that is neither hipHostMalloc'ed nor registered is pageable.  Large asynchronous copies to pageable
+// memory were seen to leave a span of the destination unwritten after hipStreamSynchronize (64 x 1080p float32 =
+// 531 MB into a fresh NumPy array: 28 MB of zeros, tools/debug notes in DESIGN.md 13.10), so pageable transfers are
+// blocking copies here -- ordered after the stream's earlier work, complete on return -- and only pinned memory is
+// copied asynchronously.
+static bool host_is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                  // (unregistered host memory: not an error for us)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
 int va_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
     VA_ENTER();
-    if (bytes)
+    if (!bytes)
+        return VA_OK;
+    if (host_is_pinned(src)) {
         VA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    } else {
+        VA_HIP(hipStreamSynchronize(as_stream(stream)));
+        VA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    }
     return VA_OK;
 }
 int va_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
 {
     VA_ENTER();
-    if (bytes)
+    if (!bytes)
+        return VA_OK;
+    if (host_is_pinned(dst)) {
         VA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    } else {
+        VA_HIP(hipStreamSynchronize(as_stream(stream)));
+        VA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    }
     return VA_OK;
 }
 int va_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)

@@ -838,11 +838,13 @@ row_is_f32_kernel(const float *__restrict__ frames, float *__restrict__ tmp, con
             // back edge arrives -- a sub-chunk's loads, then kNS stores -- and the staging at its top waits for
             // the loads only (vmcnt(2 kNS - 1 - m)); entered with the loads alone outstanding, the compiler had to
             // assume vmcnt(kNS - 1 - m), which on every later pass waited for the previous copy-out's stores as well
+#ifndef ROWIS_NO_DUMMY_STORES
             typedef unsigned int u4v __attribute__((ext_vector_type(4)));
             __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(tmp, 0, 0, 0x00027000);
 #pragma unroll
             for (int m = 0; m < kNS; m++)
                 __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, none, 0, 16 * m, 0);
+#endif
         }
         lds_barrier();                                                  // (the C of the compute waves' first row pass)
         for (int f = f0; f < f1; f++) {
