@@ -802,9 +802,8 @@ int va_mask_thinning_u8(uint8_t *img, uint8_t *scratch, uint8_t *skel, int h, in
             cur = nxt;
             nxt = t;
         }
-        VA_HIP(hipMemcpyAsync(host_cnt, cnt_dev + it0, sizeof(unsigned long long) * (size_t)k,
-                              hipMemcpyDeviceToHost, st));
         VA_HIP(hipStreamSynchronize(st));
+        VA_HIP(hipMemcpy(host_cnt, cnt_dev + it0, sizeof(unsigned long long) * (size_t)k, hipMemcpyDeviceToHost));
         for (int j = 0; j < k; j++)
             if (host_cnt[j] == 0) {
                 done_it = it0 + j;

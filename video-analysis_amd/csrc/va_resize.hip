@@ -442,8 +442,9 @@ static int launch_resize(const T *src, T *dst, int n, int sh, int sw, int c, int
     auto push = [&](const void *host, size_t bytes, void **dev) -> int {
         used = (used + 15) & ~(size_t)15;
         *dev = base + used;
-        // (pageable source: the runtime stages the bytes before hipMemcpyAsync returns)
-        VA_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, st));
+        // (pageable source that dies with this call: a blocking copy -- complete on return; the destination is this
+        //  call's own scratch, nothing on the stream uses it yet)
+        VA_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
         used += bytes;
         return VA_OK;
     };
