@@ -81,9 +81,9 @@ const char *va_version(void);
 const char *va_last_error(void);       /* message for the calling thread's last failure      */
 
 /* device memory helpers, so that a host without torch can drive the library */
-/* The stand-alone entry points lease their device scratch from the device's default memory pool,
- * whose pages va_init keeps mapped between calls; va_trim hands everything above keep_bytes back to
- * the device (synchronises it) -- e.g. before another library in the process needs the memory. */
+/* The stand-alone entry points keep their device scratch between calls (a per-stream cache of blocks, at most
+ * 6 GiB); va_trim synchronises the device and hands the cache (when it holds more than keep_bytes) and the default
+ * memory pool's pages above keep_bytes back -- e.g. before another library in the process needs the memory. */
 int va_trim(size_t keep_bytes);
 int va_malloc(void **dev_ptr, size_t bytes);
 int va_free(void *dev_ptr);

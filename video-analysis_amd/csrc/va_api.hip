@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <vector>
 #include <new>
 
 #include "va_common.h"
@@ -25,30 +26,88 @@ void set_error(const char *fmt, ...)
 }
 const char *get_error() { return g_err; }
 
-// Device scratch of the stand-alone entry points: one stream-ordered lease per call
-// (hipMallocAsync / hipFreeAsync on the call's own stream, served by the device's default memory
-// pool, whose release threshold va_init raises so that the pool keeps its pages between calls).
-// Nothing is shared between calls, so the reference's concurrent callers -- VideoPreprocessor's
-// worker threads, video/io/parallel.py:398-400 -- may use one stream each without seeing each
-// other's intermediates, and no call synchronises the device.
+// Device scratch of the stand-alone entry points: one lease per call, nothing shared between concurrent calls --
+// the reference's concurrent callers (VideoPreprocessor's worker threads, video/io/parallel.py:398-400) may use one
+// stream each without seeing each other's intermediates -- and no call synchronises the device (unless the cache
+// below overflows).
+// Scratch of the stand-alone entry points.  A block is NOT handed back to the stream-ordered allocator when a call
+// returns: hipFreeAsync right behind the kernels, followed by a large asynchronous copy to pageable host memory,
+// made the next call of the same size return a partly unwritten result (a 28 MB span of zeros in a 531 MB blur;
+// leaking the block instead made it disappear: DESIGN.md 13.10).  Blocks are kept per stream -- the next call on
+// the same stream is ordered behind the kernels that still use the block -- and released by va_trim or when more
+// than kScratchCacheCap bytes are cached (then behind a stream synchronisation).
+struct ScratchBlock {
+    void *ptr;
+    size_t bytes;
+    hipStream_t st;
+};
+static std::mutex g_scratch_mu;
+static std::vector<ScratchBlock> g_scratch_free;
+static size_t g_scratch_cached = 0;
+constexpr size_t kScratchCacheCap = 6ull << 30;
+
+static void scratch_release_all_locked()
+{
+    for (const ScratchBlock &b : g_scratch_free)
+        (void)hipFree(b.ptr);
+    g_scratch_free.clear();
+    g_scratch_cached = 0;
+}
+
 struct ScratchLease {
     void *ptr = nullptr;
+    size_t bytes = 0;
     hipStream_t st = nullptr;
-    int acquire(size_t bytes, hipStream_t stream)
+    int acquire(size_t need, hipStream_t stream)
     {
         st = stream;
-        hipError_t e = hipMallocAsync(&ptr, bytes ? bytes : 256, st);
+        need = need ? need : 256;
+        {
+            std::lock_guard<std::mutex> lock(g_scratch_mu);
+            int best = -1;
+            for (int i = 0; i < (int)g_scratch_free.size(); i++) {
+                const ScratchBlock &b = g_scratch_free[i];
+                if (b.st == st && b.bytes >= need && (best < 0 || b.bytes < g_scratch_free[best].bytes))
+                    best = i;
+            }
+            if (best >= 0 && g_scratch_free[best].bytes <= 2 * need + (1u << 20)) {
+                ptr = g_scratch_free[best].ptr;
+                bytes = g_scratch_free[best].bytes;
+                g_scratch_cached -= bytes;
+                g_scratch_free.erase(g_scratch_free.begin() + best);
+                return VA_OK;
+            }
+        }
+        hipError_t e = hipMalloc(&ptr, need);
+        if (e != hipSuccess) {                       // make room: drop what is cached, once
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+            {
+                std::lock_guard<std::mutex> lock(g_scratch_mu);
+                scratch_release_all_locked();
+            }
+            e = hipMalloc(&ptr, need);
+        }
         if (e != hipSuccess) {
             ptr = nullptr;
-            set_error("scratch: hipMallocAsync(%zu) failed: %s", bytes, hipGetErrorString(e));
+            set_error("scratch: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
             return VA_ERR_NOMEM;
         }
+        bytes = need;
         return VA_OK;
     }
     ~ScratchLease()
     {
-        if (ptr)
-            (void)hipFreeAsync(ptr, st);      // ordered after the kernels enqueued on st
+        if (!ptr)
+            return;
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (g_scratch_cached + bytes > kScratchCacheCap) {
+            (void)hipStreamSynchronize(st);          // (nothing uses the blocks any more)
+            (void)hipDeviceSynchronize();
+            scratch_release_all_locked();
+        }
+        g_scratch_free.push_back(ScratchBlock{ptr, bytes, st});
+        g_scratch_cached += bytes;
     }
 };
 
@@ -190,6 +249,11 @@ int va_trim(size_t keep_bytes)
     hipMemPool_t pool;
     VA_HIP(hipDeviceGetDefaultMemPool(&pool, g_device));
     VA_HIP(hipDeviceSynchronize());
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);      // the cached scratch blocks of the stand-alone calls
+        if (g_scratch_cached > keep_bytes)
+            scratch_release_all_locked();
+    }
     VA_HIP(hipMemPoolTrimTo(pool, keep_bytes));
     return VA_OK;
 }
